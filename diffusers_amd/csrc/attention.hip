@@ -1,0 +1,259 @@
+// attention.hip — flash-style softmax(Q K^T * scale) V for gfx950, fp16 in / fp32 softmax.
+//
+// Used for the UNet's self-attention (S = 4096/1024/256/64, head dim 40/80/160 or 64) and
+// cross-attention (S_kv = 77/152/227).  No mask in the model; keys beyond S_kv are masked here.
+//
+// MFMA path: block = 4 waves, each wave owns 32 query rows (two 16-wide tiles), the block
+// walks K/V in tiles of 64 keys staged in LDS.  The score product is issued "swapped",
+//   S^T[key][q] = K[key][:] . Q[q][:]      (v_mfma_f32_16x16x32_f16, A = K fragment, B = Q fragment)
+// so the softmax axis (keys) lies in each lane's registers + the 4 lane groups, and the exponentiated
+// S^T accumulators are *already* the B operand of the second product
+//   O^T[d][q] += V^T[d][key] * P^T[key][q]
+// whose A operand V^T is read from the row-major V tile with ds_read_b64_tr_b16 (hardware transpose).
+// Online softmax in fp32 with exp2; O^T is rescaled per q (= per lane), no cross-lane traffic for it.
+// Roofline: MFMA-bound; algorithmic flops 4*Sq*Skv*d per (batch, head).
+//
+// Plain path: one thread per (batch, head, query) — test sizes, odd head dims, cross-check.
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+struct AttnDev {
+    const half_t* Q; const half_t* K; const half_t* V; half_t* O;
+    int ldq, ldk, ldv, ldo;
+    int NB, heads, Sq, Skv, d;
+    float scale_log2e;
+};
+
+template <int DQK, int DVT>
+__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnDev p)
+{
+    constexpr int KROW = DQK + 8;        // padded K-tile row (elements)
+    constexpr int VROW = DVT * 16 + 8;   // padded V-tile row (elements); row stride stays a multiple of 16 B
+    constexpr int KS = DQK / 32;         // k-steps of the score product
+    __shared__ __attribute__((aligned(16))) half_t sK[64 * KROW];
+    __shared__ __attribute__((aligned(16))) half_t sV[64 * VROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nb = blockIdx.z, head = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wid * 32;
+    const int d = p.d;
+
+    const half_t* Qb = p.Q + (long long)nb * p.Sq * p.ldq + head * d;
+    const half_t* Kb = p.K + (long long)nb * p.Skv * p.ldk + head * d;
+    const half_t* Vb = p.V + (long long)nb * p.Skv * p.ldv + head * d;
+    half_t* Ob = p.O + (long long)nb * p.Sq * p.ldo + head * d;
+
+    // Q fragments (B operand): lane holds Q[q = q0 + 16*qt + fr][8*(4*ks+fg) .. +8]
+    half8 qf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            int q = q0 + qt * 16 + fr, c = (ks * 4 + fg) * 8;
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (q < p.Sq && c < d) v = *(const half8*)(Qb + (long long)q * p.ldq + c);
+            qf[qt][ks] = v;
+        }
+
+    floatx4 o[DVT][2];
+#pragma unroll
+    for (int a = 0; a < DVT; ++a) { o[a][0] = floatx4{0, 0, 0, 0}; o[a][1] = floatx4{0, 0, 0, 0}; }
+    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+
+    for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
+        __syncthreads();  // everyone done with the previous tile
+        // stage K: 64 rows x DQK/8 chunks ; V: 64 rows x DVT*2 chunks (zero beyond Skv / d)
+        for (int idx = tid; idx < 64 * (DQK / 8); idx += 256) {
+            int r = idx / (DQK / 8), c = (idx - r * (DQK / 8)) * 8;
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kv0 + r < p.Skv && c < d) v = *(const half8*)(Kb + (long long)(kv0 + r) * p.ldk + c);
+            *(half8*)(sK + r * KROW + c) = v;
+        }
+        for (int idx = tid; idx < 64 * (DVT * 2); idx += 256) {
+            int r = idx / (DVT * 2), c = (idx - r * (DVT * 2)) * 8;
+            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (kv0 + r < p.Skv && c < d) v = *(const half8*)(Vb + (long long)(kv0 + r) * p.ldv + c);
+            *(half8*)(sV + r * VROW + c) = v;
+        }
+        __syncthreads();
+
+        // scores S^T[key][q]: s[kt][qt][r] <-> key = kv0 + 16*kt + 4*fg + r, q = q0 + 16*qt + fr
+        floatx4 s[4][2];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) { s[kt][0] = floatx4{0, 0, 0, 0}; s[kt][1] = floatx4{0, 0, 0, 0}; }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+                half8 kf = *(const half8*)(sK + (kt * 16 + fr) * KROW + (ks * 4 + fg) * 8);
+                s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
+                s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
+            }
+        }
+        // online softmax per query column
+        half8 pf[2][2];  // [qt][k-step of 32 keys] B operand of the PV product
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = s[kt][qt][r] * p.scale_log2e;
+                    if (kv0 + kt * 16 + fg * 4 + r >= p.Skv) v = -INFINITY;
+                    s[kt][qt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            float mnew = fmaxf(mrow[qt], mx);
+            float alpha = exp2f(mrow[qt] - mnew);
+            mrow[qt] = mnew;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float e = exp2f(s[kt][qt][r] - mnew);
+                    s[kt][qt][r] = e;
+                    sum += e;
+                }
+            lrow[qt] = lrow[qt] * alpha + sum;
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+            // k-slot (fg, j): j<4 -> key tile 2*s2, reg j ; j>=4 -> key tile 2*s2+1, reg j-4
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half8 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] = (half_t)s[2 * s2][qt][r]; v[4 + r] = (half_t)s[2 * s2 + 1][qt][r]; }
+                pf[qt][s2] = v;
+            }
+        }
+        // O^T[d][q] += V^T[d][key] P^T[key][q]; A operand via transposed LDS reads:
+        // lane 4q'+p' of a 16-lane group addresses row (key) q', columns 4p'..4p'+3 and receives column (lane&15).
+        const int tq = fr >> 2, tp = fr & 3;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt) {
+                const half_t* a0 = sV + (s2 * 32 + fg * 4 + tq) * VROW + dt * 16 + tp * 4;
+                fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+                fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(a0 + 16 * VROW));
+                half8 vf;
+                half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { vf[r] = l4[r]; vf[4 + r] = h4[r]; }
+                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][s2], o[dt][0], 0, 0, 0);
+                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][s2], o[dt][1], 0, 0, 0);
+            }
+        }
+    }
+    // finish: o[dt][qt][r] <-> d index 16*dt + 4*fg + r, q = q0 + 16*qt + fr
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrow[qt];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        float inv = 1.0f / l;
+        int q = q0 + qt * 16 + fr;
+        if (q >= p.Sq) continue;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+            int c = dt * 16 + fg * 4;
+            if (c < d) {
+                half4 h = {(half_t)(o[dt][qt][0] * inv), (half_t)(o[dt][qt][1] * inv), (half_t)(o[dt][qt][2] * inv),
+                           (half_t)(o[dt][qt][3] * inv)};
+                *(half4*)(Ob + (long long)q * p.ldo + c) = h;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ plain kernel
+__global__ void attn_naive_kernel(AttnDev p)
+{
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long total = (long long)p.NB * p.heads * p.Sq;
+    if (gid >= total) return;
+    int q = (int)(gid % p.Sq);
+    int head = (int)((gid / p.Sq) % p.heads);
+    int nb = (int)(gid / ((long long)p.Sq * p.heads));
+    const int d = p.d;
+    const half_t* Qr = p.Q + ((long long)nb * p.Sq + q) * p.ldq + head * d;
+    const half_t* Kb = p.K + (long long)nb * p.Skv * p.ldk + head * d;
+    const half_t* Vb = p.V + (long long)nb * p.Skv * p.ldv + head * d;
+    half_t* Or = p.O + ((long long)nb * p.Sq + q) * p.ldo + head * d;
+    float mx = -INFINITY;
+    for (int k = 0; k < p.Skv; ++k) {
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) s += (float)Qr[c] * (float)Kb[(long long)k * p.ldk + c];
+        mx = fmaxf(mx, s * p.scale_log2e);
+    }
+    float l = 0.f;
+    for (int k = 0; k < p.Skv; ++k) {
+        float s = 0.f;
+        for (int c = 0; c < d; ++c) s += (float)Qr[c] * (float)Kb[(long long)k * p.ldk + c];
+        l += exp2f(s * p.scale_log2e - mx);
+    }
+    const float inv = 1.0f / l;
+    for (int c0 = 0; c0 < d; c0 += 8) {
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < p.Skv; ++k) {
+            float s = 0.f;
+            for (int c = 0; c < d; ++c) s += (float)Qr[c] * (float)Kb[(long long)k * p.ldk + c];
+            float e = exp2f(s * p.scale_log2e - mx);
+            for (int j = 0; j < 8 && c0 + j < d; ++j) acc[j] += e * (float)Vb[(long long)k * p.ldv + c0 + j];
+        }
+        for (int j = 0; j < 8 && c0 + j < d; ++j) Or[c0 + j] = (half_t)(acc[j] * inv);
+    }
+}
+
+bool attention_mfma_supported(const AttnArgs& a)
+{
+    if (a.d % 8 || a.d > 160) return false;
+    if (a.ldq % 8 || a.ldk % 8 || a.ldv % 8 || a.ldo % 4) return false;
+    if ((reinterpret_cast<uintptr_t>(a.Q) | reinterpret_cast<uintptr_t>(a.K) | reinterpret_cast<uintptr_t>(a.V)) & 15) return false;
+    if (reinterpret_cast<uintptr_t>(a.O) & 7) return false;
+    return true;
+}
+
+template <int DQK, int DVT>
+static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
+{
+    dim3 grid(cdiv(p.Sq, 128), p.heads, p.NB);
+    hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT>), grid, dim3(256), 0, ctx.stream, p);
+}
+
+void launch_attention(const LaunchCtx& ctx, const AttnArgs& a)
+{
+    SDE_REQUIRE(a.NB > 0 && a.heads > 0 && a.Sq > 0 && a.Skv > 0 && a.d > 0, SDE_ERR_INVALID_ARGUMENT, "attention: empty problem");
+    AttnDev p{a.Q, a.K, a.V, a.O, a.ldq, a.ldk, a.ldv, a.ldo, a.NB, a.heads, a.Sq, a.Skv, a.d,
+              a.scale * 1.44269504088896340736f};
+    const double flops = 4.0 * a.NB * a.heads * (double)a.Sq * a.Skv * a.d;
+    const double bytes = 2.0 * a.NB * a.heads * ((double)a.Sq * a.d * 2 + (double)a.Skv * a.d * 2);
+    if (!ctx.force_naive && attention_mfma_supported(a)) {
+        ProfScope ps(ctx, a.Sq == a.Skv ? "attn_self_mfma" : "attn_cross_mfma", flops, bytes);
+        const int d = a.d;
+        if (d <= 16) launch_attn_t<32, 1>(ctx, p);
+        else if (d <= 32) launch_attn_t<32, 2>(ctx, p);
+        else if (d <= 48) launch_attn_t<64, 3>(ctx, p);
+        else if (d <= 64) launch_attn_t<64, 4>(ctx, p);
+        else if (d <= 80) launch_attn_t<96, 5>(ctx, p);
+        else if (d <= 96) launch_attn_t<96, 6>(ctx, p);
+        else if (d <= 128) launch_attn_t<128, 8>(ctx, p);
+        else launch_attn_t<160, 10>(ctx, p);
+    } else {
+        ProfScope ps(ctx, "attn_plain", flops, bytes);
+        long long total = (long long)a.NB * a.heads * a.Sq;
+        hipLaunchKernelGGL(attn_naive_kernel, dim3((unsigned)cdiv64(total, 128)), dim3(128), 0, ctx.stream, p);
+    }
+    HIP_CHECK(hipGetLastError());
+}

@@ -1,0 +1,823 @@
+// engine.cpp — the C ABI (include/sdengine.h): engine lifecycle, the two "session.run" replacements,
+// the on-device txt2img loop, scheduler handles, measurement hooks.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <memory>
+#include <mutex>
+#include <random>
+
+#include "model.h"
+#include "scheduler.h"
+
+// ------------------------------------------------------------------------------------------ errors
+static thread_local std::string g_last_error;
+void sde_set_last_error(const std::string& m) { g_last_error = m; }
+
+template <typename F>
+static sde_status guarded(F&& f)
+{
+    try {
+        f();
+        return SDE_OK;
+    } catch (const SdeError& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_last_error = "out of host memory";
+        return SDE_ERR_DEVICE;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return SDE_ERR_INVALID_ARGUMENT;
+    } catch (...) {
+        g_last_error = "unknown error";
+        return SDE_ERR_INVALID_ARGUMENT;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ profiler
+struct Profiler {
+    bool enabled = false;
+    struct Class { std::string name; uint64_t launches = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::vector<Class> classes;
+    struct Pending { int cls; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    hipStream_t stream = nullptr;
+
+    hipEvent_t get_event()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        return e;
+    }
+    int class_of(const char* name)
+    {
+        for (size_t i = 0; i < classes.size(); ++i) if (classes[i].name == name) return (int)i;
+        classes.push_back(Class{name});
+        return (int)classes.size() - 1;
+    }
+    void resolve()
+    {
+        if (pending.empty()) return;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (auto& p : pending) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) classes[(size_t)p.cls].ms += ms;
+            pool.push_back(p.a); pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    ~Profiler() { for (auto& p : pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); } for (auto e : pool) (void)hipEventDestroy(e); }
+};
+
+ProfScope::ProfScope(const LaunchCtx& c, const char* name, double flops, double bytes) : ctx(c), slot(-1)
+{
+    Profiler* p = c.prof;
+    if (!p || !p->enabled) return;
+    int cls = p->class_of(name);
+    p->classes[(size_t)cls].launches += 1;
+    p->classes[(size_t)cls].flops += flops;
+    p->classes[(size_t)cls].bytes += bytes;
+    Profiler::Pending pe{cls, p->get_event(), p->get_event()};
+    (void)hipEventRecord(pe.a, c.stream);
+    p->pending.push_back(pe);
+    slot = (int)p->pending.size() - 1;
+}
+ProfScope::~ProfScope()
+{
+    if (slot < 0) return;
+    Profiler* p = ctx.prof;
+    (void)hipEventRecord(p->pending[(size_t)slot].b, ctx.stream);
+}
+
+// ------------------------------------------------------------------------------------------ engine
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    void ensure(size_t bytes, bool zero = false, hipStream_t s = nullptr)
+    {
+        if (bytes <= cap) return;
+        if (p) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipFree(p)); p = nullptr; cap = 0; }
+        HIP_CHECK(hipMalloc(&p, bytes));
+        cap = bytes;
+        if (zero) HIP_CHECK(hipMemsetAsync(p, 0, bytes, s));
+    }
+    template <typename T> T* as() { return (T*)p; }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+
+struct sde_engine {
+    int device = 0;
+    sde_engine_opts opts{};
+    hipStream_t stream = nullptr;
+    Profiler prof;
+    LaunchCtx ctx;
+    std::unique_ptr<OnnxModel> unet_onnx, vae_onnx;  // kept only during construction
+    WeightBuilder wb;
+    UNetModel unet;
+    VaeDecoderModel vae;
+    bool has_unet = false, has_vae = false;
+    Arena arena;
+    DevBuf arena_buf, zeros, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps;
+    std::vector<half_t*> kv_ptrs;
+    std::mutex mu;  // one forward at a time per engine (reference: Session is Send+Sync; here calls serialize)
+    // cached arena sizing
+    long long unet_key = -1, vae_key = -1;
+    size_t unet_peak = 0, vae_peak = 0;
+
+    ~sde_engine()
+    {
+        (void)hipSetDevice(device);
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    }
+};
+
+static void engine_activate(sde_engine* e) { HIP_CHECK(hipSetDevice(e->device)); }
+
+static void ensure_arena(sde_engine* e, size_t bytes)
+{
+    if (bytes > e->arena_buf.cap) e->arena_buf.ensure(bytes + (bytes >> 3));
+    e->arena.base = e->arena_buf.as<char>();
+    e->arena.cap = e->arena_buf.cap;
+}
+
+static void setup_kv(sde_engine* e, int N, int S)
+{
+    size_t total = 0;
+    for (int i = 0; i < e->unet.n_transformers; ++i) total += (e->unet.kv_elems(i, N, S) + 127) & ~(size_t)127;
+    e->kvbuf.ensure(total * sizeof(half_t));
+    e->kv_ptrs.resize((size_t)e->unet.n_transformers);
+    size_t off = 0;
+    for (int i = 0; i < e->unet.n_transformers; ++i) {
+        e->kv_ptrs[(size_t)i] = e->kvbuf.as<half_t>() + off;
+        off += (e->unet.kv_elems(i, N, S) + 127) & ~(size_t)127;
+    }
+}
+
+// runs the UNet on device buffers; sizes the arena with a dry pass when the shape changes
+static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w, float t, const half_t* ehs_h, int S, bool fill_kv,
+                     float* out)
+{
+    SDE_REQUIRE(e->has_unet, SDE_ERR_MODEL, "engine was created without a UNet");
+    const long long key = ((long long)N << 40) ^ ((long long)h << 28) ^ ((long long)w << 16) ^ S;
+    if (key != e->unet_key) {
+        Arena dry; dry.dry = true;
+        Exec dx{e->ctx, &dry};
+        std::vector<half_t*> fake((size_t)e->unet.n_transformers, (half_t*)nullptr);
+        e->unet.forward(dx, nullptr, N, h, w, t, nullptr, S, fake.data(), true, nullptr);
+        e->unet_peak = dry.peak; e->unet_key = key;
+    }
+    ensure_arena(e, std::max(e->unet_peak, e->vae_peak));
+    e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false;
+    Exec ex{e->ctx, &e->arena};
+    e->unet.forward(ex, x_packed, N, h, w, t, ehs_h, S, e->kv_ptrs.data(), fill_kv, out);
+}
+
+static void vae_run(sde_engine* e, const half_t* x_packed, int B, int h, int w, int epi, float* out)
+{
+    SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "engine was created without a VAE decoder");
+    const long long key = ((long long)B << 40) ^ ((long long)h << 20) ^ w;
+    if (key != e->vae_key) {
+        Arena dry; dry.dry = true;
+        Exec dx{e->ctx, &dry};
+        e->vae.forward(dx, nullptr, B, h, w, epi, nullptr);
+        e->vae_peak = dry.peak; e->vae_key = key;
+    }
+    ensure_arena(e, std::max(e->unet_peak, e->vae_peak));
+    e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false;
+    Exec ex{e->ctx, &e->arena};
+    e->vae.forward(ex, x_packed, B, h, w, epi, out);
+}
+
+// decode_latents on device: latents f32 NCHW (device) -> images f32 NHWC (device)
+static void decode_dev(sde_engine* e, const float* d_latents, int B, int h, int w, int epi, float* d_out)
+{
+    // impl_main.rs:399 — `1.0 / 0.18215 * latents`; the TOML scale-factor is ignored there too
+    const float scale = epi == EPI_IMAGE ? 1.0f / 0.18215f : 1.0f;
+    // the reference decodes one image per ORT call (impl_main.rs:402-405); batching is numerically identical per image.
+    // Chunk so the 512^2 activations stay within a few GB.
+    const int chunk = std::max(1, std::min(B, 8));
+    const int up = e->vae.upscale();
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        e->vae_in.ensure((size_t)nb * h * w * VaeDecoderModel::kInPad * sizeof(half_t));
+        launch_pack_nchw(e->ctx, d_latents + (size_t)b0 * e->vae.latent_channels * h * w, e->vae_in.as<half_t>(), nb, e->vae.latent_channels, h, w,
+                         VaeDecoderModel::kInPad, scale);
+        vae_run(e, e->vae_in.as<half_t>(), nb, h, w, epi, d_out + (size_t)b0 * e->vae.out_channels * h * up * w * up);
+    }
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: library / engine
+extern "C" {
+
+const char* sde_last_error(void) { return g_last_error.c_str(); }
+const char* sde_version(void) { return "sdengine 0.1 (gfx950)"; }
+int sde_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void sde_engine_opts_default(sde_engine_opts* o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->device_id = 0; o->dtype = SDE_F16; o->force_naive = 0; o->load_unet = 1; o->load_vae = 1; o->num_heads_override = 0;
+}
+
+static sde_status engine_create_impl(const std::string& unet_path, const std::string& vae_path, const sde_engine_opts* opts_in, sde_engine** out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(out, SDE_ERR_INVALID_ARGUMENT, "out pointer is null");
+        *out = nullptr;
+        sde_engine_opts o;
+        if (opts_in) o = *opts_in; else sde_engine_opts_default(&o);
+        SDE_REQUIRE(o.dtype == SDE_F16, SDE_ERR_INVALID_ARGUMENT, "only dtype f16 is implemented in this build (bf16/f32 engines are not)");
+        int ndev = sde_device_count();
+        SDE_REQUIRE(ndev > 0, SDE_ERR_DEVICE, "no HIP device visible: the engine has no CPU fallback");
+        SDE_REQUIRE(o.device_id >= 0 && o.device_id < ndev, SDE_ERR_DEVICE, "device_id out of range");
+        std::unique_ptr<sde_engine> e(new sde_engine());
+        e->device = o.device_id; e->opts = o;
+        HIP_CHECK(hipSetDevice(e->device));
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, e->device));
+        SDE_REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, SDE_ERR_DEVICE,
+                    std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
+        HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->prof.stream = e->stream;
+        e->zeros.ensure(4096, true, e->stream);
+        e->ctx.stream = e->stream; e->ctx.prof = &e->prof; e->ctx.zeros = e->zeros.as<half_t>(); e->ctx.force_naive = o.force_naive != 0;
+        e->wb.ctx = e->ctx; e->wb.ctx.prof = nullptr;
+        if (o.load_unet && !unet_path.empty()) {
+            OnnxModel m; WeightMap w;
+            onnx_load(unet_path, m);
+            bind_weights(m, w);
+            e->wb.w = &w; e->wb.params = 0;
+            e->unet.build(m, w, e->wb, o.num_heads_override);
+            HIP_CHECK(hipStreamSynchronize(e->stream));  // repack kernels read mapped files' staging copies
+            e->has_unet = true;
+        }
+        if (o.load_vae && !vae_path.empty()) {
+            OnnxModel m; WeightMap w;
+            onnx_load(vae_path, m);
+            bind_weights(m, w);
+            e->wb.w = &w; e->wb.params = 0;
+            e->vae.build(m, w, e->wb);
+            HIP_CHECK(hipStreamSynchronize(e->stream));
+            e->has_vae = true;
+        }
+        e->wb.w = nullptr;
+        e->wb.release_staging();
+        SDE_REQUIRE(e->has_unet || e->has_vae, SDE_ERR_INVALID_ARGUMENT, "nothing to load");
+        *out = e.release();
+    });
+}
+
+sde_status sde_engine_create(const char* model_dir, const sde_engine_opts* opts, sde_engine** out)
+{
+    std::string up, vp;
+    sde_status st = guarded([&] {
+        SDE_REQUIRE(model_dir, SDE_ERR_INVALID_ARGUMENT, "model_dir is null");
+        PykeConfig cfg;
+        pyke_config_load(model_dir, cfg);
+        up = std::string(model_dir) + "/" + cfg.unet_path;
+        vp = std::string(model_dir) + "/" + cfg.vae_decoder_path;
+    });
+    if (st != SDE_OK) return st;
+    return engine_create_impl(up, vp, opts, out);
+}
+
+sde_status sde_engine_create_from_files(const char* unet_onnx, const char* vae_decoder_onnx, const sde_engine_opts* opts, sde_engine** out)
+{
+    return engine_create_impl(unet_onnx ? unet_onnx : "", vae_decoder_onnx ? vae_decoder_onnx : "", opts, out);
+}
+
+void sde_engine_destroy(sde_engine* e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    delete e;
+}
+
+sde_status sde_engine_info(const sde_engine* e, sde_model_info* info)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && info, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        memset(info, 0, sizeof(*info));
+        info->unet_loaded = e->has_unet; info->vae_loaded = e->has_vae;
+        if (e->has_unet) {
+            const UNetModel& u = e->unet;
+            info->in_channels = u.in_channels; info->out_channels = u.out_channels; info->n_levels = u.n_levels;
+            info->layers_per_block = u.layers_per_block; info->cross_attention_dim = u.ctx_dim; info->use_linear_projection = u.linear_proj;
+            for (int i = 0; i < u.n_levels && i < 8; ++i) { info->block_out_channels[i] = u.boc[(size_t)i]; info->num_heads[i] = u.heads[(size_t)i]; info->down_attn[i] = u.down_attn[(size_t)i]; }
+            info->unet_params = u.n_params;
+        }
+        if (e->has_vae) {
+            const VaeDecoderModel& v = e->vae;
+            info->vae_n_levels = v.n_levels; info->vae_layers_per_block = v.layers_per_block; info->vae_latent_channels = v.latent_channels;
+            info->vae_out_channels = v.out_channels;
+            for (int i = 0; i < v.n_levels && i < 8; ++i) info->vae_block_out_channels[i] = v.boc[(size_t)i];
+            info->vae_params = v.n_params;
+        }
+    });
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: UNet / VAE calls
+static void check_unet_args(const sde_engine* e, const void* sample, int N, int h, int w, const void* ehs, int S, int D, const void* out)
+{
+    SDE_REQUIRE(e && sample && ehs && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+    SDE_REQUIRE(e->has_unet, SDE_ERR_MODEL, "engine was created without a UNet");
+    SDE_REQUIRE(N > 0 && h > 0 && w > 0 && S > 0, SDE_ERR_INVALID_ARGUMENT, "empty tensor");
+    SDE_REQUIRE(D == e->unet.ctx_dim, SDE_ERR_INVALID_ARGUMENT,
+                "encoder_hidden_states width " + std::to_string(D) + " != cross_attention_dim " + std::to_string(e->unet.ctx_dim));
+}
+
+sde_status sde_unet_forward_dev(sde_engine* e, const float* d_sample, int N, int h, int w, float timestep, const float* d_ehs, int S, int D,
+                                float* d_out)
+{
+    return guarded([&] {
+        check_unet_args(e, d_sample, N, h, w, d_ehs, S, D, d_out);
+        std::lock_guard<std::mutex> lk(e->mu);
+        engine_activate(e);
+        const int Cp = UNetModel::kInPad;
+        e->x_packed.ensure((size_t)N * h * w * Cp * sizeof(half_t));
+        e->ehs_h.ensure((size_t)N * S * D * sizeof(half_t));
+        setup_kv(e, N, S);
+        launch_pack_nchw(e->ctx, d_sample, e->x_packed.as<half_t>(), N, e->unet.in_channels, h, w, Cp, 1.0f);
+        launch_f32_to_f16(e->ctx, d_ehs, e->ehs_h.as<half_t>(), (int64_t)N * S * D);
+        unet_run(e, e->x_packed.as<half_t>(), N, h, w, timestep, e->ehs_h.as<half_t>(), S, true, d_out);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+    });
+}
+
+sde_status sde_unet_forward(sde_engine* e, const float* sample, int N, int h, int w, float timestep, const float* ehs, int S, int D, float* out)
+{
+    return guarded([&] {
+        check_unet_args(e, sample, N, h, w, ehs, S, D, out);
+        size_t ns, ne;
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            engine_activate(e);
+            ns = (size_t)N * e->unet.in_channels * h * w; ne = (size_t)N * S * D;
+            e->scratch_f.ensure((ns + ne + (size_t)N * e->unet.out_channels * h * w) * sizeof(float));
+            HIP_CHECK(hipMemcpy(e->scratch_f.p, sample, ns * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(e->scratch_f.as<float>() + ns, ehs, ne * 4, hipMemcpyHostToDevice));
+        }
+        float* d = e->scratch_f.as<float>();
+        sde_status st = sde_unet_forward_dev(e, d, N, h, w, timestep, d + ns, S, D, d + ns + ne);
+        if (st != SDE_OK) sde_fail(st, g_last_error);
+        HIP_CHECK(hipMemcpy(out, d + ns + ne, (size_t)N * e->unet.out_channels * h * w * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+static sde_status vae_common(sde_engine* e, const float* latents, int B, int h, int w, float* out, int epi, bool dev)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && latents && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "engine was created without a VAE decoder");
+        SDE_REQUIRE(B > 0 && h > 0 && w > 0, SDE_ERR_INVALID_ARGUMENT, "empty tensor");
+        std::lock_guard<std::mutex> lk(e->mu);
+        engine_activate(e);
+        const int up = e->vae.upscale();
+        const size_t nl = (size_t)B * e->vae.latent_channels * h * w, no = (size_t)B * e->vae.out_channels * h * up * w * up;
+        if (dev) {
+            decode_dev(e, latents, B, h, w, epi, out);
+            HIP_CHECK(hipStreamSynchronize(e->stream));
+        } else {
+            e->latents.ensure(nl * 4);
+            e->images.ensure(no * 4);
+            HIP_CHECK(hipMemcpy(e->latents.p, latents, nl * 4, hipMemcpyHostToDevice));
+            decode_dev(e, e->latents.as<float>(), B, h, w, epi, e->images.as<float>());
+            HIP_CHECK(hipStreamSynchronize(e->stream));
+            HIP_CHECK(hipMemcpy(out, e->images.p, no * 4, hipMemcpyDeviceToHost));
+        }
+    });
+}
+sde_status sde_vae_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images) { return vae_common(e, latents, B, h, w, images, EPI_IMAGE, false); }
+sde_status sde_vae_decode_dev(sde_engine* e, const float* latents, int B, int h, int w, float* images) { return vae_common(e, latents, B, h, w, images, EPI_IMAGE, true); }
+sde_status sde_vae_decoder_run(sde_engine* e, const float* latents, int B, int h, int w, float* sample) { return vae_common(e, latents, B, h, w, sample, EPI_NCHW_F32, false); }
+
+sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && latents && images && B > 0 && h > 0 && w > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
+        std::lock_guard<std::mutex> lk(e->mu);
+        engine_activate(e);
+        const size_t nl = (size_t)B * 4 * h * w, no = (size_t)B * h * w * 3;
+        e->latents.ensure(nl * 4); e->images.ensure(no * 4);
+        HIP_CHECK(hipMemcpy(e->latents.p, latents, nl * 4, hipMemcpyHostToDevice));
+        launch_approx_decode(e->ctx, e->latents.as<float>(), e->images.as<float>(), B, h, w);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        HIP_CHECK(hipMemcpy(images, e->images.p, no * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: schedulers
+void sde_sched_cfg_default(int kind, sde_sched_cfg* c)
+{
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->num_train_timesteps = 1000; c->beta_start = 0.0001f; c->beta_end = 0.02f; c->beta_schedule = SDE_BETA_LINEAR;
+    c->prediction_type = SDE_PRED_EPSILON; c->reference_quirks = 1;
+    c->solver_order = 2; c->lower_order_final = 1;                 // dpm_solver_multistep.rs:80-92
+    c->clip_sample = kind == SDE_SCHED_DDIM ? 1 : 0;               // ddim.rs:59-67 ; ddpm.rs:40 (derive Default => false)
+    c->set_alpha_to_one = 1; c->steps_offset = 0; c->variance_type = 0;
+}
+void sde_sched_cfg_sd_v1(int kind, sde_sched_cfg* c)
+{
+    if (!c) return;
+    sde_sched_cfg_default(kind, c);
+    c->beta_start = 0.00085f; c->beta_end = 0.012f; c->beta_schedule = SDE_BETA_SCALED_LINEAR;
+    if (kind == SDE_SCHED_DDIM) { c->clip_sample = 0; c->set_alpha_to_one = 0; c->steps_offset = 1; }  // ddim.rs:275-286
+}
+
+sde_status sde_scheduler_create(int kind, const sde_sched_cfg* cfg, sde_scheduler** out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(out, SDE_ERR_INVALID_ARGUMENT, "out pointer is null");
+        *out = nullptr;
+        sde_sched_cfg c;
+        if (cfg) c = *cfg; else sde_sched_cfg_sd_v1(kind, &c);
+        std::unique_ptr<sde_scheduler> s(new sde_scheduler());
+        s->init(kind, c);
+        *out = s.release();
+    });
+}
+void sde_scheduler_destroy(sde_scheduler* s) { delete s; }
+int sde_scheduler_order(const sde_scheduler*) { return 1; }  // every scheduler in the reference returns 1
+int sde_scheduler_len(const sde_scheduler* s) { return s ? s->T : 0; }
+sde_status sde_scheduler_set_timesteps(sde_scheduler* s, int n)
+{
+    return guarded([&] { SDE_REQUIRE(s, SDE_ERR_INVALID_ARGUMENT, "null scheduler"); s->set_timesteps(n); });
+}
+int sde_scheduler_num_timesteps(const sde_scheduler* s) { return s ? (int)s->timesteps.size() : 0; }
+sde_status sde_scheduler_timesteps(const sde_scheduler* s, float* out, int capacity)
+{
+    return guarded([&] {
+        SDE_REQUIRE(s && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(capacity >= (int)s->timesteps.size(), SDE_ERR_INVALID_ARGUMENT, "capacity too small");
+        std::copy(s->timesteps.begin(), s->timesteps.end(), out);
+    });
+}
+sde_status sde_scheduler_sigmas(const sde_scheduler* s, float* out, int capacity, int* n_out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(s && n_out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        *n_out = (int)s->sigmas.size();
+        if (out) { SDE_REQUIRE(capacity >= *n_out, SDE_ERR_INVALID_ARGUMENT, "capacity too small"); std::copy(s->sigmas.begin(), s->sigmas.end(), out); }
+    });
+}
+float sde_scheduler_init_noise_sigma(const sde_scheduler* s) { return s ? s->init_noise_sigma : 0.f; }
+
+// Host-pointer mirrors of the tensor methods: they run the SAME device kernels as the fused loop (on the
+// current device's null stream) — there is no CPU implementation of the step arithmetic in the product.
+namespace {
+struct TmpDev {
+    std::vector<void*> ptrs;
+    float* up(const float* h, size_t n) { float* d = nullptr; HIP_CHECK(hipMalloc((void**)&d, n * 4)); ptrs.push_back(d); if (h) HIP_CHECK(hipMemcpy(d, h, n * 4, hipMemcpyHostToDevice)); return d; }
+    ~TmpDev() { for (void* p : ptrs) (void)hipFree(p); }
+};
+void require_device() { SDE_REQUIRE(sde_device_count() > 0, SDE_ERR_DEVICE, "no HIP device visible: scheduler tensor methods run on the GPU"); }
+}  // namespace
+
+sde_status sde_scheduler_scale_model_input(sde_scheduler* s, const float* sample, size_t n, float timestep, float* out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(s && sample && out && n > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
+        require_device();
+        float div = s->input_scale_divisor(timestep);
+        TmpDev t; LaunchCtx ctx;
+        float* dx = t.up(sample, n); float* dy = t.up(nullptr, n);
+        launch_vec_op(ctx, dx, nullptr, dy, (int64_t)n, 0, div, 0.f);
+        HIP_CHECK(hipMemcpy(out, dy, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+sde_status sde_scheduler_step(sde_scheduler* s, const float* model_output, float timestep, const float* sample, const float* noise, size_t n,
+                              float* prev_sample)
+{
+    return guarded([&] {
+        SDE_REQUIRE(s && model_output && sample && prev_sample && n > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
+        require_device();
+        StepPlan p;
+        s->plan(timestep, p);
+        SDE_REQUIRE(!p.needs_noise || noise, SDE_ERR_INVALID_ARGUMENT, "this scheduler step needs a noise tensor");
+        TmpDev t; LaunchCtx ctx;
+        StepArgs a;
+        a.kind = p.kind; a.pred = p.pred; a.B = 1; a.C = 1; a.H = 1; a.W = (int)n; a.cfg = 0;
+        a.model_out = t.up(model_output, n); a.latents = t.up(sample, n); a.noise = p.needs_noise ? t.up(noise, n) : nullptr;
+        for (int i = 0; i < 8; ++i) a.c[i] = p.c[i];
+        a.clip = p.clip; a.nhist = p.nhist;
+        for (int i = 0; i < 4; ++i) a.lms_c[i] = p.lms_c[i];
+        if (p.nhist > 0 || s->kind == SDE_SCHED_LMS) {
+            if (s->mirror_hist_n != n) {
+                for (float* q : s->mirror_hist) if (q) (void)hipFree(q);
+                s->mirror_hist.assign(4, nullptr);
+                for (auto& q : s->mirror_hist) { HIP_CHECK(hipMalloc((void**)&q, n * 4)); HIP_CHECK(hipMemset(q, 0, n * 4)); }
+                s->mirror_hist_n = n;
+            }
+            for (int i = 0; i < 4; ++i) a.hist[i] = s->mirror_hist[(size_t)i];
+        }
+        launch_cfg_step(ctx, a);
+        HIP_CHECK(hipMemcpy(prev_sample, a.latents, n * 4, hipMemcpyDeviceToHost));
+        if (s->kind == SDE_SCHED_DPMPP && p.nhist > 0) std::swap(s->mirror_hist[0], s->mirror_hist[1]);
+        if (s->kind == SDE_SCHED_LMS) std::rotate(s->mirror_hist.begin(), s->mirror_hist.begin() + 3, s->mirror_hist.end());  // [0] becomes the free slot
+        s->advance(p);
+    });
+}
+
+sde_status sde_scheduler_add_noise(sde_scheduler* s, const float* original, const float* noise, size_t n, float timestep, float* out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(s && original && noise && out && n > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
+        require_device();
+        float a, b;
+        s->add_noise_coeffs(timestep, a, b);
+        TmpDev t; LaunchCtx ctx;
+        float* dx = t.up(original, n); float* dn = t.up(noise, n); float* dy = t.up(nullptr, n);
+        launch_vec_op(ctx, dx, dn, dy, (int64_t)n, 1, a, b);
+        HIP_CHECK(hipMemcpy(out, dy, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: txt2img
+void sde_txt2img_opts_default(sde_txt2img_opts* o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->height = 512; o->width = 512; o->guidance_scale = 7.5f; o->steps = 25; o->batch_size = 1;  // impl_txt2img.rs:50-65
+    o->callback_frequency = 1;
+}
+
+static void fill_normal(std::mt19937_64& rng, float* dst, size_t n)
+{
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (size_t i = 0; i < n; ++i) dst[i] = nd(rng);
+}
+
+sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_opts* o, float* images_out, sde_run_stats* stats)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && sch && o, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(o->height % 8 == 0 && o->width % 8 == 0 && o->height > 0 && o->width > 0, SDE_ERR_INVALID_ARGUMENT,
+                    "`width` (" + std::to_string(o->width) + ") and `height` (" + std::to_string(o->height) +
+                        ") must be divisible by 8 for Stable Diffusion");  // impl_txt2img.rs:251-253
+        SDE_REQUIRE(e->has_unet, SDE_ERR_MODEL, "engine was created without a UNet");
+        SDE_REQUIRE(o->skip_decode || e->has_vae, SDE_ERR_MODEL, "engine was created without a VAE decoder");
+        SDE_REQUIRE(o->skip_decode || images_out, SDE_ERR_INVALID_ARGUMENT, "images_out is null");
+        SDE_REQUIRE(o->batch_size > 0 && o->steps > 0 && o->ehs && o->S > 0, SDE_ERR_INVALID_ARGUMENT, "bad batch/steps/embeddings");
+        SDE_REQUIRE(o->D == e->unet.ctx_dim, SDE_ERR_INVALID_ARGUMENT, "text embedding width does not match the UNet's cross_attention_dim");
+        std::lock_guard<std::mutex> lk(e->mu);
+        engine_activate(e);
+        const int B = o->batch_size, h = o->height / 8, w = o->width / 8, S = o->S, D = o->D, C = e->unet.in_channels;
+        const bool cfg = o->guidance_scale > 1.0f;  // :258
+        const int N = cfg ? 2 * B : B;
+        const size_t per = (size_t)B * C * h * w;
+        const int Cp = UNetModel::kInPad;
+        hipStream_t st = e->stream;
+
+        const uint64_t seed = o->has_seed ? o->seed : std::random_device{}();
+        std::mt19937_64 rng(seed), sched_rng(seed + 31337);  // :249,267 (engine RNG streams; not rand::StdRng-compatible)
+
+        sch->set_timesteps(o->steps);                         // :264
+        const std::vector<float> ts = sch->timesteps;         // :269
+        const int nt = (int)ts.size();
+        SDE_REQUIRE(nt > 0, SDE_ERR_SCHEDULER, "scheduler produced no timesteps");
+        long long num_warmup = (long long)nt - (long long)o->steps * 1;  // :270 ; negative == usize wrap-around in release builds
+        if (num_warmup < 0) num_warmup = (1LL << 62);
+
+        // ---- device state
+        e->latents.ensure(per * 4);
+        e->model_out.ensure((size_t)N * C * h * w * 4);
+        e->x_packed.ensure((size_t)N * h * w * Cp * sizeof(half_t));
+        HIP_CHECK(hipMemsetAsync(e->x_packed.p, 0, (size_t)N * h * w * Cp * sizeof(half_t), st));
+        e->ehs_h.ensure((size_t)N * S * D * sizeof(half_t));
+        setup_kv(e, N, S);
+        float* d_lat = e->latents.as<float>();
+        std::vector<float> host_tmp;
+        if (o->buffers_on_device) {
+            launch_f32_to_f16(e->ctx, o->ehs, e->ehs_h.as<half_t>(), (int64_t)N * S * D);
+        } else {
+            e->ehs_f.ensure((size_t)N * S * D * 4);
+            HIP_CHECK(hipMemcpyAsync(e->ehs_f.p, o->ehs, (size_t)N * S * D * 4, hipMemcpyHostToDevice, st));
+            launch_f32_to_f16(e->ctx, e->ehs_f.as<float>(), e->ehs_h.as<half_t>(), (int64_t)N * S * D);
+        }
+        if (o->init_latents) {
+            HIP_CHECK(hipMemcpyAsync(d_lat, o->init_latents, per * 4, o->buffers_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        } else {
+            host_tmp.resize(per);
+            fill_normal(rng, host_tmp.data(), per);           // :261-262
+            HIP_CHECK(hipMemcpyAsync(d_lat, host_tmp.data(), per * 4, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+        }
+        launch_vec_op(e->ctx, d_lat, nullptr, d_lat, (int64_t)per, 2, sch->init_noise_sigma, 0.f);  // :265
+        for (auto& hb : e->hist) hb.ensure(per * 4, true, st);
+        float* hist[4] = {e->hist[0].as<float>(), e->hist[1].as<float>(), e->hist[2].as<float>(), e->hist[3].as<float>()};
+        const bool want_taps = o->noise_pred_out != nullptr;
+        if (want_taps) e->taps.ensure(per * 4);
+        if (o->has_rescale_cfg && cfg) e->scratch_f.ensure(4096);
+
+        hipEvent_t ev0, ev1, ev2;
+        HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventCreate(&ev2));
+        HIP_CHECK(hipEventRecord(ev0, st));
+
+        // first model input: scale_model_input(concat(latents, latents), t0)  (:273-278)
+        {
+            float div = sch->input_scale_divisor(ts[0]);
+            launch_pack_latents(e->ctx, d_lat, e->x_packed.as<half_t>(), B, cfg ? 2 : 1, C, h, w, Cp, 1.0f / div);
+        }
+        int unet_calls = 0;
+        std::vector<float> cb_buf;
+        for (int i = 0; i < nt; ++i) {
+            const float t = ts[(size_t)i];
+            unet_run(e, e->x_packed.as<half_t>(), N, h, w, t, e->ehs_h.as<half_t>(), S, i == 0, e->model_out.as<float>());  // :283
+            ++unet_calls;
+            StepPlan p;
+            sch->plan(t, p);
+            StepArgs a;
+            a.kind = p.kind; a.pred = p.pred; a.B = B; a.C = C; a.H = h; a.W = w; a.cfg = cfg ? 1 : 0; a.guidance = o->guidance_scale;
+            a.model_out = e->model_out.as<float>(); a.latents = d_lat;
+            for (int k = 0; k < 8; ++k) a.c[k] = p.c[k];
+            a.clip = p.clip; a.nhist = p.nhist;
+            for (int k = 0; k < 4; ++k) { a.lms_c[k] = p.lms_c[k]; a.hist[k] = hist[k]; }
+            if (p.needs_noise) {
+                e->noise.ensure(per * 4);
+                if (o->step_noise && o->buffers_on_device) a.noise = o->step_noise + (size_t)i * per;
+                else {
+                    const float* src;
+                    if (o->step_noise) src = o->step_noise + (size_t)i * per;
+                    else { host_tmp.resize(per); fill_normal(sched_rng, host_tmp.data(), per); src = host_tmp.data(); }
+                    HIP_CHECK(hipMemcpyAsync(e->noise.p, src, per * 4, hipMemcpyHostToDevice, st));
+                    HIP_CHECK(hipStreamSynchronize(st));
+                    a.noise = e->noise.as<float>();
+                }
+            }
+            if (o->has_rescale_cfg && cfg) {
+                float* ws = e->scratch_f.as<float>();
+                launch_cfg_rescale_factor(e->ctx, e->model_out.as<float>(), B, (int64_t)per, o->guidance_scale, o->rescale_cfg, ws + 16, ws);
+                a.rescale_factor = ws;
+            }
+            if (i + 1 < nt) {
+                a.next_input = e->x_packed.as<half_t>(); a.Cpad = Cp;
+                a.next_input_scale = 1.0f / sch->input_scale_divisor(ts[(size_t)i + 1]);
+            }
+            if (want_taps) a.eps_out = e->taps.as<float>();
+            launch_cfg_step(e->ctx, a);                                                                  // :288-304
+            sch->advance(p);
+            if (sch->kind == SDE_SCHED_DPMPP && p.nhist > 0) std::swap(hist[0], hist[1]);
+            if (sch->kind == SDE_SCHED_LMS) std::rotate(hist, hist + 3, hist + 4);
+            if (want_taps) HIP_CHECK(hipMemcpyAsync(o->noise_pred_out + (size_t)i * per, e->taps.p, per * 4, hipMemcpyDeviceToHost, st));
+            if (o->latents_out) HIP_CHECK(hipMemcpyAsync(o->latents_out + (size_t)i * per, d_lat, per * 4, hipMemcpyDeviceToHost, st));
+            if (want_taps || o->latents_out) HIP_CHECK(hipStreamSynchronize(st));
+            // callbacks (:306-323)
+            if (o->callback && o->callback_kind != SDE_CB_NONE) {
+                const int freq = std::max(1, o->callback_frequency);
+                if (i == nt - 1 || ((long long)(i + 1) > num_warmup && (i + 1) % 1 == 0)) {
+                    int keep = 1;
+                    if (o->callback_kind == SDE_CB_PROGRESS && i % freq == 0) keep = o->callback(i, t, nullptr, 0, o->callback_user);
+                    else if (o->callback_kind == SDE_CB_LATENTS && i % freq == 0) {
+                        cb_buf.resize(per);
+                        HIP_CHECK(hipMemcpyAsync(cb_buf.data(), d_lat, per * 4, hipMemcpyDeviceToHost, st));
+                        HIP_CHECK(hipStreamSynchronize(st));
+                        keep = o->callback(i, t, cb_buf.data(), per, o->callback_user);
+                    } else if (o->callback_kind == SDE_CB_DECODED && i != 0 && i % freq == 0) {
+                        SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "Decoded callback needs the VAE decoder");
+                        const size_t no = (size_t)B * o->height * o->width * 3;
+                        e->images.ensure(no * 4);
+                        decode_dev(e, d_lat, B, h, w, EPI_IMAGE, e->images.as<float>());
+                        cb_buf.resize(no);
+                        HIP_CHECK(hipMemcpyAsync(cb_buf.data(), e->images.p, no * 4, hipMemcpyDeviceToHost, st));
+                        HIP_CHECK(hipStreamSynchronize(st));
+                        keep = o->callback(i, t, cb_buf.data(), no, o->callback_user);
+                    } else if (o->callback_kind == SDE_CB_APPROXIMATE && i != 0 && i % freq == 0) {
+                        const size_t no = (size_t)B * h * w * 3;
+                        e->images.ensure(no * 4);
+                        launch_approx_decode(e->ctx, d_lat, e->images.as<float>(), B, h, w);
+                        cb_buf.resize(no);
+                        HIP_CHECK(hipMemcpyAsync(cb_buf.data(), e->images.p, no * 4, hipMemcpyDeviceToHost, st));
+                        HIP_CHECK(hipStreamSynchronize(st));
+                        keep = o->callback(i, t, cb_buf.data(), no, o->callback_user);
+                    }
+                    if (!keep) break;  // the reference breaks out of the loop and still decodes (:319-326)
+                }
+            }
+        }
+        HIP_CHECK(hipEventRecord(ev1, st));
+        if (o->final_latents_out) HIP_CHECK(hipMemcpyAsync(o->final_latents_out, d_lat, per * 4, hipMemcpyDeviceToHost, st));
+        if (!o->skip_decode) {                                                                           // :326
+            const size_t no = (size_t)B * o->height * o->width * 3;
+            if (o->buffers_on_device) decode_dev(e, d_lat, B, h, w, EPI_IMAGE, images_out);
+            else {
+                e->images.ensure(no * 4);
+                decode_dev(e, d_lat, B, h, w, EPI_IMAGE, e->images.as<float>());
+            }
+            HIP_CHECK(hipEventRecord(ev2, st));
+            if (!o->buffers_on_device) HIP_CHECK(hipMemcpyAsync(images_out, e->images.p, no * 4, hipMemcpyDeviceToHost, st));
+        } else HIP_CHECK(hipEventRecord(ev2, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+        if (stats) {
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2);
+            stats->unet_calls = unet_calls; stats->unet_ms = a; stats->vae_ms = b; stats->total_ms = a + b;
+        }
+        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
+    });
+}
+
+// ------------------------------------------------------------------------------------------ C ABI: measurement + test hooks
+sde_status sde_profile_enable(sde_engine* e, int enable)
+{
+    return guarded([&] { SDE_REQUIRE(e, SDE_ERR_INVALID_ARGUMENT, "null engine"); engine_activate(e); e->prof.resolve(); e->prof.enabled = enable != 0; });
+}
+sde_status sde_profile_reset(sde_engine* e)
+{
+    return guarded([&] { SDE_REQUIRE(e, SDE_ERR_INVALID_ARGUMENT, "null engine"); engine_activate(e); e->prof.resolve(); e->prof.classes.clear(); });
+}
+sde_status sde_profile_get(sde_engine* e, sde_kernel_stat* out, int capacity, int* n_out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && n_out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        engine_activate(e);
+        e->prof.resolve();
+        *n_out = (int)e->prof.classes.size();
+        for (int i = 0; out && i < capacity && i < *n_out; ++i) {
+            const auto& c = e->prof.classes[(size_t)i];
+            memset(&out[i], 0, sizeof(out[i]));
+            strncpy(out[i].name, c.name.c_str(), sizeof(out[i].name) - 1);
+            out[i].launches = c.launches; out[i].total_ms = c.ms; out[i].flops = c.flops; out[i].bytes = c.bytes;
+        }
+    });
+}
+sde_status sde_synchronize(sde_engine* e)
+{
+    return guarded([&] { SDE_REQUIRE(e, SDE_ERR_INVALID_ARGUMENT, "null engine"); engine_activate(e); HIP_CHECK(hipStreamSynchronize(e->stream)); });
+}
+
+sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin, const float* w, const float* bias, int Cout,
+                         int ksize, int stride, int upsample, float* out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && x && w && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
+        std::lock_guard<std::mutex> lk(e->mu);
+        engine_activate(e);
+        LaunchCtx ctx = e->ctx; ctx.force_naive = naive != 0;
+        const int taps = ksize * ksize;
+        const int Hv = upsample ? 2 * Hi : Hi, Wv = upsample ? 2 * Wi : Wi;
+        const int Ho = ksize == 3 ? (Hv - 1) / stride + 1 : Hv, Wo = ksize == 3 ? (Wv - 1) / stride + 1 : Wv;
+        const size_t nx = (size_t)NB * Hi * Wi * Cin, nw = (size_t)Cout * Cin * taps, no = (size_t)NB * Ho * Wo * Cout;
+        const int Npad = gemm_npad(Cout), K = taps * Cin;
+        DevBuf dxf, dxh, dwf, dwh, dbias, doh, dof;
+        dxf.ensure(nx * 4); dxh.ensure(nx * 2); dwf.ensure(nw * 4); dwh.ensure((size_t)Npad * K * 2); doh.ensure(no * 2); dof.ensure(no * 4);
+        HIP_CHECK(hipMemcpy(dxf.p, x, nx * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dwf.p, w, nw * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemsetAsync(dwh.p, 0, (size_t)Npad * K * 2, e->stream));
+        if (bias) { dbias.ensure((size_t)Cout * 4); HIP_CHECK(hipMemcpy(dbias.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
+        launch_f32_to_f16(ctx, dxf.as<float>(), dxh.as<half_t>(), (int64_t)nx);
+        RepackArgs r;
+        r.src = dwf.p; r.src_is_f16 = 0; r.O = Cout; r.I = Cin; r.KH = ksize; r.KW = ksize; r.in_out = 0; r.dst = dwh.as<half_t>();
+        r.dst_row0 = 0; r.Ipad = Cin; r.i0 = 0; r.Kdst = K;
+        launch_repack(ctx, r);
+        GemmArgs g;
+        g.A0 = dxh.as<half_t>(); g.lda0 = Cin; g.C0 = Cin; g.taps = taps; g.stride = ksize == 3 ? stride : 1; g.ups = ksize == 3 ? upsample : 0;
+        g.Hi = Hv; g.Wi = Wv; g.Ho = Ho; g.Wo = Wo; g.M = NB * Ho * Wo; g.N = Cout; g.K = K;
+        g.W = dwh.as<half_t>(); g.Npad = Npad; g.bias = bias ? dbias.as<float>() : nullptr; g.D = doh.as<half_t>(); g.ldd = Cout;
+        launch_gemm(ctx, g);
+        launch_f16_to_f32(ctx, doh.as<half_t>(), dof.as<float>(), (int64_t)no);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        HIP_CHECK(hipMemcpy(out, dof.p, no * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const float* k, const float* v, int NB, int heads, int Sq, int Skv, int d,
+                              float* out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && q && k && v && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        std::lock_guard<std::mutex> lk(e->mu);
+        engine_activate(e);
+        LaunchCtx ctx = e->ctx; ctx.force_naive = naive != 0;
+        const int C = heads * d;
+        const size_t nq = (size_t)NB * Sq * C, nk = (size_t)NB * Skv * C;
+        DevBuf f, qh, kh, vh, oh, of;
+        f.ensure(std::max(nq, nk) * 4); qh.ensure(nq * 2); kh.ensure(nk * 2); vh.ensure(nk * 2); oh.ensure(nq * 2); of.ensure(nq * 4);
+        auto up = [&](const float* src, size_t n, DevBuf& dst) {
+            HIP_CHECK(hipMemcpy(f.p, src, n * 4, hipMemcpyHostToDevice));
+            launch_f32_to_f16(ctx, f.as<float>(), dst.as<half_t>(), (int64_t)n);
+            HIP_CHECK(hipStreamSynchronize(e->stream));
+        };
+        up(q, nq, qh); up(k, nk, kh); up(v, nk, vh);
+        AttnArgs a;
+        a.Q = qh.as<half_t>(); a.K = kh.as<half_t>(); a.V = vh.as<half_t>(); a.O = oh.as<half_t>();
+        a.ldq = a.ldk = a.ldv = a.ldo = C; a.NB = NB; a.heads = heads; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.0f / sqrtf((float)d);
+        launch_attention(ctx, a);
+        launch_f16_to_f32(ctx, oh.as<half_t>(), of.as<float>(), (int64_t)nq);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        HIP_CHECK(hipMemcpy(out, of.p, nq * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"

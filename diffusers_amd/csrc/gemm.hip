@@ -1,0 +1,384 @@
+// gemm.hip — fp16 GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+//   D[m][n] = epilogue( sum_k A[m][k] * W[n][k] )
+//
+// A is an NHWC activation tensor read through an implicit im2col: for taps=9 the K axis runs over
+// (ky,kx,cin) of a 3x3/pad-1 convolution (stride 1 or 2, optional on-the-fly nearest 2x upsample,
+// optional channel concat of two sources); for taps=1 it is a plain row-major matrix.
+// W is [Npad][K] fp16 (OHWI order), prepared once by the loader.
+//
+// MFMA path: 256 threads = 4 waves (2x2), block tile BM x BN x 64, v_mfma_f32_16x16x32_f16,
+// both operand tiles staged with global_load_lds_dwordx4 (16 B/lane, LDS image lane-linear, XOR swizzle
+// applied on the per-lane SOURCE address and again on the ds_read_b128 address), two LDS stages,
+// one barrier per K-step, XCD-aware block remap.  Roofline: MFMA-bound (2*M*N*K flop).
+// The MFMA is issued as D^T = W * A^T so each lane ends up with 4 consecutive n for one m (8-byte stores).
+//
+// Plain path: one thread per output element, same index maps, used for shapes the MFMA path does not take
+// (K-chunk not a multiple of 64, tiny test models) and as an on-device cross-check.
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+struct GemmDev {
+    const half_t* A0; const half_t* A1;
+    int C0, C1, lda0, lda1;
+    int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws;
+    const half_t* W; int Npad;
+    const float* bias; const half_t* R; int ldr;
+    half_t* D; float* Df; int ldd; int epi; float alpha;
+    long long sA, sW, sD, sR;
+    const half_t* zeros;
+    int nbm, nbn;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ------------------------------------------------------------------------------------------ epilogue (shared)
+// Handles 4 consecutive columns n..n+3 of row m held in v[0..3].
+__device__ __forceinline__ void epilogue4(const GemmDev& p, int m, int n, floatx4 v, floatx4 vg, long long zD, long long zR)
+{
+    if (m >= p.M) return;
+    if (p.epi == EPI_STD) {
+        if (n >= p.N) return;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = v[r] * p.alpha;
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] += p.bias[n + r];
+        }
+        if (n + 3 < p.N) {
+            if (p.R) {
+                half4 rr = *(const half4*)(p.R + zR + (long long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += (float)rr[r];
+            }
+            half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                float x = o[r];
+                if (p.R) x += (float)p.R[zR + (long long)m * p.ldr + n + r];
+                p.D[zD + (long long)m * p.ldd + n + r] = (half_t)x;
+            }
+        }
+    } else if (p.epi == EPI_GEGLU) {
+        // v = value columns, vg = gate columns for output columns j..j+3 (j passed in n)
+        int half_n = p.N >> 1;
+        if (n >= half_n) return;
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = v[r], g = vg[r];
+            if (p.bias && n + r < half_n) { a += p.bias[n + r]; g += p.bias[half_n + n + r]; }
+            h[r] = (half_t)(a * gelu_erf(g));
+        }
+        if (n + 3 < half_n) *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
+        else for (int r = 0; r < 4 && n + r < half_n; ++r) p.D[zD + (long long)m * p.ldd + n + r] = h[r];
+    } else if (p.epi == EPI_NCHW_F32) {
+        int hw = p.Ho * p.Wo;
+        int nb = m / hw, pix = m - nb * hw;
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r] + (p.bias ? p.bias[n + r] : 0.f);
+            p.Df[zD + ((long long)nb * p.N + n + r) * hw + pix] = x;
+        }
+    } else if (p.epi == EPI_IMAGE) {
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r] + (p.bias ? p.bias[n + r] : 0.f);
+            x = x / 2.0f + 0.5f;
+            x = fminf(fmaxf(x, 0.0f), 1.0f);
+            p.Df[zD + (long long)m * p.N + n + r] = x;
+        }
+    } else {  // EPI_TRANS
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r] * p.alpha + (p.bias ? p.bias[n + r] : 0.f);
+            p.D[zD + (long long)(n + r) * p.ldd + m] = (half_t)x;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ MFMA kernel
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int AP = BM / 32, BP = BN / 32;  // glds passes per thread (32 rows of 128 B per pass)
+    constexpr int MTW = BM / 32, NTW = BN / 32;  // 16-wide tiles per wave (wave tile = BM/2 x BN/2)
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const int z = blockIdx.z;
+
+    // XCD-aware bijective remap: blocks b, b+8, b+16.. share an XCD (L2); give each XCD a contiguous tile range.
+    const int nwg = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.nbn, tn = bid - tm * p.nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const half_t* A0 = p.A0 + z * p.sA;
+    const half_t* A1 = p.A1 ? p.A1 + z * p.sA : nullptr;
+    const half_t* Wp = p.W + z * p.sW;
+
+    // per-thread staging geometry
+    const int srow = tid >> 3;                       // row inside a 32-row pass
+    const int lchunk = (tid & 7) ^ (srow & 7);       // logical 16-B chunk this lane fetches (XOR swizzle on the source)
+    int a_base[AP];                                  // conv: pixel index of image origin ; linear: row index
+    int a_y[AP], a_x[AP];                            // conv: oy*stride-1, ox*stride-1
+    bool a_ok[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        int m = m0 + i * 32 + srow;
+        a_ok[i] = m < p.M;
+        if (CONV) {
+            int hw = p.Ho * p.Wo;
+            int nb = m / hw, rem = m - nb * hw;
+            int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_base[i] = nb * p.Hs * p.Ws;
+            a_y[i] = oy * p.stride - 1;
+            a_x[i] = ox * p.stride - 1;
+        } else {
+            a_base[i] = m; a_y[i] = 0; a_x[i] = 0;
+        }
+    }
+    const half_t* w_ptr[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) w_ptr[i] = Wp + (long long)(n0 + i * 32 + srow) * p.K + lchunk * 8;
+
+    const int Ctot = p.C0 + p.C1;
+    const int nk = p.K >> 6;
+
+    auto stage = [&](int kt, int buf) {
+        char* sa = smem + buf * STAGE;
+        char* sb = sa + A_BYTES;
+        const int k0 = kt << 6;
+        int tap = 0, c0 = k0;
+        if (CONV) { tap = k0 / Ctot; c0 = k0 - tap * Ctot; }
+        const half_t* src = A0; int ld = p.lda0; int cc = c0;
+        if (c0 >= p.C0) { src = A1; ld = p.lda1; cc = c0 - p.C0; }
+        int dy = 0, dx = 0;
+        if (CONV) { dy = tap / 3; dx = tap - dy * 3; }
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const half_t* g;
+            if (CONV) {
+                int iy = a_y[i] + dy, ix = a_x[i] + dx;
+                bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                long long pix = a_base[i] + (iy >> p.ups) * p.Ws + (ix >> p.ups);
+                g = ok ? src + pix * ld + cc + lchunk * 8 : p.zeros;
+            } else {
+                g = a_ok[i] ? src + (long long)a_base[i] * ld + cc + lchunk * 8 : p.zeros;
+            }
+            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(sa + (i * 256 + wid * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(w_ptr[i] + k0), LDS_PTR(sb + (i * 256 + wid * 64) * 16), 16, 0, 0);
+    };
+
+    floatx4 acc[NTW][MTW];
+#pragma unroll
+    for (int a = 0; a < NTW; ++a)
+#pragma unroll
+        for (int b = 0; b < MTW; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* sa = smem + buf * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 wf[NTW], af[MTW];
+            const int q = kk * 4 + fg;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                int row = wn * (BN / 2) + nt * 16 + fr;
+                wf[nt] = *(const half8*)(sb + (row * 8 + (q ^ (row & 7))) * 16);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) {
+                int row = wm * (BM / 2) + mt * 16 + fr;
+                af[mt] = *(const half8*)(sa + (row * 8 + (q ^ (row & 7))) * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue: acc[nt][mt][r] <-> n = n0 + wn*BN/2 + nt*16 + 4*fg + r ; m = m0 + wm*BM/2 + mt*16 + fr
+    const long long zD = z * p.sD, zR = z * p.sR;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+        const int m = m0 + wm * (BM / 2) + mt * 16 + fr;
+        if (p.epi == EPI_GEGLU) {
+#pragma unroll
+            for (int nt = 0; nt + 1 < NTW; nt += 2) {
+                int ncol = n0 + wn * (BN / 2) + nt * 16;      // interleaved column of the value block
+                int j = (ncol >> 1) + 4 * fg;                 // output column
+                epilogue4(p, m, j, acc[nt][mt], acc[nt + 1][mt], zD, zR);
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                int n = n0 + wn * (BN / 2) + nt * 16 + 4 * fg;
+                epilogue4(p, m, n, acc[nt][mt], acc[nt][mt], zD, zR);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ plain kernel
+__global__ void gemm_naive_kernel(GemmDev p)
+{
+    const int z = blockIdx.z;
+    const half_t* A0 = p.A0 + z * p.sA;
+    const half_t* A1 = p.A1 ? p.A1 + z * p.sA : nullptr;
+    const half_t* Wp = p.W + z * p.sW;
+    const int Nout = p.epi == EPI_GEGLU ? (p.N >> 1) : p.N;
+    const int groups = (Nout + 3) >> 2;
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)p.M * groups) return;
+    const int m = (int)(gid / groups), n4 = (int)(gid - (long long)m * groups) * 4;
+    const int Ctot = p.C0 + p.C1;
+    int nb = 0, oy = 0, ox = 0;
+    if (p.taps == 9) {
+        int hw = p.Ho * p.Wo;
+        nb = m / hw; int rem = m - nb * hw; oy = rem / p.Wo; ox = rem - oy * p.Wo;
+    }
+    floatx4 v = {0, 0, 0, 0}, vg = {0, 0, 0, 0};
+    for (int r = 0; r < 4; ++r) {
+        int n = n4 + r;
+        if (n >= Nout) break;
+        // weight rows: GEGLU weights are interleaved in 16-blocks: out col j -> value row 32*(j/16)+j%16, gate row +16
+        int wrow = n, grow = 0;
+        if (p.epi == EPI_GEGLU) { wrow = 32 * (n >> 4) + (n & 15); grow = wrow + 16; }
+        float s = 0.f, sg = 0.f;
+        for (int tap = 0; tap < p.taps; ++tap) {
+            long long pix; bool ok = true;
+            if (p.taps == 9) {
+                int iy = oy * p.stride - 1 + tap / 3, ix = ox * p.stride - 1 + tap % 3;
+                ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                pix = (long long)nb * p.Hs * p.Ws + (iy >> p.ups) * p.Ws + (ix >> p.ups);
+            } else pix = m;
+            if (!ok) continue;
+            const half_t* wr = Wp + (long long)wrow * p.K + tap * Ctot;
+            const half_t* wg = Wp + (long long)grow * p.K + tap * Ctot;
+            const half_t* a0 = A0 + pix * p.lda0;
+            for (int c = 0; c < p.C0; ++c) {
+                float x = (float)a0[c];
+                s += x * (float)wr[c];
+                if (p.epi == EPI_GEGLU) sg += x * (float)wg[c];
+            }
+            if (p.C1) {
+                const half_t* a1 = A1 + pix * p.lda1;
+                for (int c = 0; c < p.C1; ++c) {
+                    float x = (float)a1[c];
+                    s += x * (float)wr[p.C0 + c];
+                    if (p.epi == EPI_GEGLU) sg += x * (float)wg[p.C0 + c];
+                }
+            }
+        }
+        v[r] = s; vg[r] = sg;
+    }
+    epilogue4(p, m, n4, v, vg, z * p.sD, z * p.sR);
+}
+
+// ------------------------------------------------------------------------------------------ host side
+int gemm_npad(int N) { return (N % 160 == 0 || N % 128 == 0) ? N : round_up(N, 128); }
+
+static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
+{
+    GemmDev p;
+    p.A0 = a.A0; p.A1 = a.A1; p.C0 = a.C0; p.C1 = a.C1; p.lda0 = a.lda0; p.lda1 = a.lda1;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.taps = a.taps; p.stride = a.stride; p.ups = a.ups;
+    p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
+    p.Hs = a.ups ? a.Hi / 2 : a.Hi; p.Ws = a.ups ? a.Wi / 2 : a.Wi;
+    p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
+    p.epi = a.epi; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
+    p.nbm = p.nbn = 0;
+    return p;
+}
+
+bool gemm_mfma_supported(const GemmArgs& a)
+{
+    const int Ctot = a.C0 + a.C1;
+    if (a.K % 64 || a.K != a.taps * Ctot) return false;
+    if (a.taps == 9 && (Ctot % 64 || a.C0 % 64)) return false;   // a 64-wide K chunk must stay inside one tap / one source
+    if (a.taps == 1 && a.C1 && a.C0 % 64) return false;
+    if (a.lda0 % 8 || (a.C1 && a.lda1 % 8)) return false;          // 16-B aligned source chunks
+    if (a.Npad % 128 && a.Npad % 160) return false;
+    if (a.epi == EPI_GEGLU && (a.N % 64 || a.Npad % 128)) return false;
+    if ((a.epi == EPI_STD || a.epi == EPI_GEGLU) && (a.ldd % 4 || (a.R && a.ldr % 4))) return false;
+    if ((reinterpret_cast<uintptr_t>(a.A0) | reinterpret_cast<uintptr_t>(a.W)) & 15) return false;
+    if ((a.sA | a.sW) % 8 || (a.sD | a.sR) % 4) return false;
+    return true;
+}
+
+template <int BM, int BN, bool CONV>
+static void launch_mfma(const LaunchCtx& ctx, GemmDev& p, int batch)
+{
+    static bool attr_set = false;
+    constexpr int smem = 2 * (BM + BN) * 128;
+    auto kern = gemm_mfma_kernel<BM, BN, CONV>;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_set = true;
+    }
+    p.nbm = cdiv(p.M, BM);
+    p.nbn = p.Npad / BN;
+    dim3 grid(p.nbm * p.nbn, 1, batch);
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx.stream, p);
+}
+
+void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
+{
+    SDE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.A0 && a.W, SDE_ERR_INVALID_ARGUMENT, "launch_gemm: empty problem");
+    SDE_REQUIRE(a.K == a.taps * (a.C0 + a.C1), SDE_ERR_INVALID_ARGUMENT, "launch_gemm: K != taps*(C0+C1)");
+    SDE_REQUIRE(a.N <= a.Npad, SDE_ERR_INVALID_ARGUMENT, "launch_gemm: N > Npad");
+    if (a.taps == 9)
+        SDE_REQUIRE(a.M % (a.Ho * a.Wo) == 0 && a.Ho > 0 && a.Wo > 0 && a.Hi > 0 && a.Wi > 0, SDE_ERR_INVALID_ARGUMENT,
+                    "launch_gemm: conv geometry");
+    GemmDev p = to_dev(ctx, a);
+    const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
+    const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (a.R ? 2 : 1)) * 2.0 * a.batch;
+    if (!ctx.force_naive && gemm_mfma_supported(a)) {
+        ProfScope ps(ctx, a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU ? "gemm_geglu_mfma" : "gemm_mfma"), flops, bytes);
+        const bool small_m = a.M <= 2048;
+        const bool bn160 = (a.Npad % 160 == 0) && a.epi != EPI_GEGLU;
+        if (a.taps == 9) {
+            if (bn160) { if (small_m) launch_mfma<64, 160, true>(ctx, p, a.batch); else launch_mfma<128, 160, true>(ctx, p, a.batch); }
+            else       { if (small_m) launch_mfma<64, 128, true>(ctx, p, a.batch); else launch_mfma<128, 128, true>(ctx, p, a.batch); }
+        } else {
+            if (bn160) { if (small_m) launch_mfma<64, 160, false>(ctx, p, a.batch); else launch_mfma<128, 160, false>(ctx, p, a.batch); }
+            else       { if (small_m) launch_mfma<64, 128, false>(ctx, p, a.batch); else launch_mfma<128, 128, false>(ctx, p, a.batch); }
+        }
+    } else {
+        ProfScope ps(ctx, a.taps == 9 ? "conv3x3_plain" : "gemm_plain", flops, bytes);
+        const int Nout = a.epi == EPI_GEGLU ? a.N / 2 : a.N;
+        long long total = (long long)a.M * ((Nout + 3) / 4);
+        dim3 grid((unsigned)cdiv64(total, 256), 1, a.batch);
+        hipLaunchKernelGGL(gemm_naive_kernel, grid, dim3(256), 0, ctx.stream, p);
+    }
+    HIP_CHECK(hipGetLastError());
+}

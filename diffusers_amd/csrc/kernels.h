@@ -1,0 +1,155 @@
+// kernels.h — launch interface of the hand-written gfx950 kernels.
+//
+// Layout conventions inside the engine:
+//   activations  : fp16, NHWC == [rows = NB*H*W][C] row-major ("token-major"), C % 8 == 0
+//   weights      : fp16, [Npad][K] row-major with K = taps*Cin in (ky,kx,cin) order (OHWI)
+//   accumulators : fp32
+#pragma once
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------ profiling
+struct Profiler;  // engine.cpp
+struct LaunchCtx {
+    hipStream_t stream = nullptr;
+    Profiler* prof = nullptr;
+    const half_t* zeros = nullptr;  // >= 256 B of device zeros (source for padded taps / tail rows)
+    bool force_naive = false;
+};
+// RAII bracket: records HIP events around a launch when profiling is on.
+struct ProfScope {
+    ProfScope(const LaunchCtx& ctx, const char* name, double flops, double bytes);
+    ~ProfScope();
+    const LaunchCtx& ctx;
+    int slot;
+};
+
+// ------------------------------------------------------------------------------------------ GEMM / implicit-GEMM conv
+enum GemmEpilogue {
+    EPI_STD = 0,       // D[m][n] = half(alpha*acc + bias[n] + R[m][n])
+    EPI_GEGLU = 1,     // weights row-interleaved in 16-blocks (value,gate); D[m][j] = (a+ba) * gelu_erf(g+bg), ldd >= N/2
+    EPI_NCHW_F32 = 2,  // Df[(nb*N + n)*HoWo + pix] = acc + bias          (UNet / VAE graph output)
+    EPI_IMAGE = 3,     // Df[m*N + n] = clamp((acc + bias)/2 + 0.5, 0, 1)   (decode_latents post-processing)
+    EPI_TRANS = 4      // D[n*ldd + m] = half(alpha*acc + bias[n])
+};
+
+struct GemmArgs {
+    // A operand: rows m in [0,M); for conv, m = (nb*Ho + oy)*Wo + ox and K runs over (tap, channel)
+    const half_t* A0 = nullptr;
+    const half_t* A1 = nullptr;  // second source of a channel concat (or null)
+    int C0 = 0, C1 = 0;          // channels taken from A0 / A1 per pixel (C0 + C1 = Cin)
+    int lda0 = 0, lda1 = 0;      // row strides in elements
+    int M = 0, N = 0, K = 0;     // K = taps * (C0 + C1)
+    int taps = 1;                // 1 (linear / 1x1) or 9 (3x3, pad 1)
+    int stride = 1;              // conv stride (1 or 2)
+    int ups = 0;                 // 1: the source tensor is (Hi/2 x Wi/2), nearest-upsampled 2x on the fly
+    int Hi = 0, Wi = 0;          // (virtual) input height/width; Ho, Wo output
+    int Ho = 0, Wo = 0;
+    const half_t* W = nullptr;   // [Npad][K]
+    int Npad = 0;
+    const float* bias = nullptr; // [N] or null
+    const half_t* R = nullptr;   // residual [M][ldr] or null
+    int ldr = 0;
+    half_t* D = nullptr;
+    float* Df = nullptr;
+    int ldd = 0;
+    int epi = EPI_STD;
+    float alpha = 1.0f;
+    // batching over blockIdx.z (independent problems with identical shapes)
+    int batch = 1;
+    long long sA = 0, sW = 0, sD = 0, sR = 0;
+    const char* tag = "gemm";
+};
+
+void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a);
+// true if the MFMA path can take this problem (alignment rules in gemm.hip)
+bool gemm_mfma_supported(const GemmArgs& a);
+int gemm_npad(int N);  // weight rows must be padded to this
+
+// ------------------------------------------------------------------------------------------ attention
+struct AttnArgs {
+    const half_t* Q = nullptr; const half_t* K = nullptr; const half_t* V = nullptr; half_t* O = nullptr;
+    int ldq = 0, ldk = 0, ldv = 0, ldo = 0;  // row strides (elements)
+    int NB = 0, heads = 0, Sq = 0, Skv = 0, d = 0;
+    float scale = 1.0f;
+};
+void launch_attention(const LaunchCtx& ctx, const AttnArgs& a);
+bool attention_mfma_supported(const AttnArgs& a);
+
+// ------------------------------------------------------------------------------------------ normalisation
+// GroupNorm over NHWC (optionally a channel concat of two sources), fused affine (+SiLU).
+struct GroupNormArgs {
+    const half_t* X0 = nullptr; const half_t* X1 = nullptr;
+    int C0 = 0, C1 = 0;
+    int NB = 0, HW = 0, groups = 32;
+    float eps = 1e-5f;
+    const float* gamma = nullptr; const float* beta = nullptr;  // [C0+C1] fp32
+    bool silu = false;
+    half_t* Y = nullptr;     // [NB*HW][C0+C1]
+    float* ws = nullptr;     // workspace, >= groupnorm_ws_floats(...) floats
+};
+size_t groupnorm_ws_floats(int NB, int C, int HW);
+void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a);
+
+void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows, int C, const float* gamma,
+                      const float* beta, float eps);
+// in-place softmax over the last dim of a [rows][cols] fp16 matrix (fp32 math)
+void launch_softmax_rows(const LaunchCtx& ctx, half_t* X, int64_t rows, int cols);
+
+// ------------------------------------------------------------------------------------------ element-wise / edge kernels
+// NCHW f32 [NB,C,H,W] -> NHWC fp16 [NB*H*W][Cpad] (channels >= C zero), scaled
+void launch_pack_nchw(const LaunchCtx& ctx, const float* x, half_t* y, int NB, int C, int H, int W, int Cpad, float scale);
+void launch_f32_to_f16(const LaunchCtx& ctx, const float* x, half_t* y, int64_t n);
+void launch_f16_to_f32(const LaunchCtx& ctx, const half_t* x, float* y, int64_t n);
+// NHWC fp16 -> NHWC f32 (test hook)
+// sinusoidal timestep embedding, flip_sin_to_cos=True, shift 0: out[0:dim/2]=cos, [dim/2:]=sin  (f32)
+void launch_timestep_embedding(const LaunchCtx& ctx, float t, float* out, int dim);
+// y[n] = act(W[n][:] . x + bias[n]),  W fp16 [N][K], x f32 [K]; pre_silu applies SiLU to x first
+void launch_gemv(const LaunchCtx& ctx, const half_t* W, const float* x, const float* bias, float* y, int N, int K,
+                 bool pre_silu, bool post_silu);
+// approximate_decode_latents: latents NCHW f32 [B,4,h,w] -> NHWC f32 [B,h,w,3] clamped
+void launch_approx_decode(const LaunchCtx& ctx, const float* lat, float* img, int B, int h, int w);
+
+// weight repack: src (f32 or f16) -> dst fp16 [rows][Kdst], see loader for the index maps
+struct RepackArgs {
+    const void* src = nullptr; int src_is_f16 = 0;
+    // logical source tensor W[o][i][ky][kx] (conv, OIHW) or W[o][i] (linear);  in_out=1: stored [i][o]
+    int O = 0, I = 0, KH = 1, KW = 1, in_out = 0;
+    half_t* dst = nullptr; int dst_row0 = 0;  // destination row offset
+    int Ipad = 0;                              // per-tap channel count in dst (>= I, zero padded)
+    int i0 = 0;                                // channel offset inside the tap where this source starts
+    int Kdst = 0;                              // dst row length
+    int geglu_half = 0;                        // >0: row o -> interleaved row (16-block value/gate), value = geglu_half
+};
+void launch_repack(const LaunchCtx& ctx, const RepackArgs& a);
+
+// ------------------------------------------------------------------------------------------ fused CFG + scheduler step
+enum StepKind { STEP_EULER = 0, STEP_EULER_A = 1, STEP_DPM1 = 2, STEP_DPM2M = 3, STEP_DDIM = 4, STEP_DDPM = 5, STEP_LMS = 6 };
+struct StepArgs {
+    int kind = 0;
+    int pred = 0;            // sde_prediction_type
+    int B = 0, C = 4, H = 0, W = 0;
+    int cfg = 0;             // 1: model_out holds [2B] (uncond first)
+    float guidance = 1.0f;
+    const float* rescale_factor = nullptr;  // device scalar (m*ro_pos/ro_cfg + 1-m) or null
+    const float* model_out = nullptr;       // f32 NCHW [N,4,h,w]
+    float* latents = nullptr;               // f32 NCHW [B,4,h,w], updated in place
+    const float* noise = nullptr;           // f32 [B,4,h,w] or null
+    float c[8] = {0};                       // scheduler coefficients (meaning per kind, scheduler.cpp)
+    int clip = 0;
+    float* hist[4] = {nullptr, nullptr, nullptr, nullptr};  // history buffers (DPM 2M: x0; LMS: derivatives), f32 [B,4,h,w]
+    int nhist = 0;
+    float lms_c[4] = {0};
+    float next_input_scale = 1.0f;          // next step's scale_model_input factor (1/sqrt(sigma^2+1) or 1)
+    half_t* next_input = nullptr;           // fp16 NHWC [N][h*w][Cpad] for the next UNet call (or null)
+    int Cpad = 64;
+    float* eps_out = nullptr;               // optional f32 [B,4,h,w] tap: CFG-combined model output
+};
+void launch_cfg_step(const LaunchCtx& ctx, const StepArgs& a);
+// latents -> scaled, duplicated, packed UNet input (first step / standalone scale_model_input)
+void launch_pack_latents(const LaunchCtx& ctx, const float* latents, half_t* packed, int B, int dup, int C, int H, int W,
+                         int Cpad, float scale);
+// CFG-rescale factor (impl_txt2img.rs:293-297): out[0] = m*std(text)/std(x_cfg) + (1-m)
+void launch_cfg_rescale_factor(const LaunchCtx& ctx, const float* model_out, int B, int64_t per_half, float guidance,
+                               float m, float* ws, float* out);
+// mode 0: out = x / a ; mode 1: out = a*x + b*y ; mode 2: out = x * a   (f32 vectors)
+void launch_vec_op(const LaunchCtx& ctx, const float* x, const float* y, float* out, int64_t n, int mode, float a, float b);

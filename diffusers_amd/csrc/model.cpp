@@ -1,0 +1,554 @@
+// model.cpp — weight upload/repack and the UNet / VAE-decoder forward graphs.  See model.h.
+#include "model.h"
+
+#include <cmath>
+
+// ------------------------------------------------------------------------------------------ WeightBuilder
+WeightBuilder::~WeightBuilder()
+{
+    for (void* p : allocs) (void)hipFree(p);
+    if (staging) (void)hipFree(staging);
+}
+void* WeightBuilder::dmalloc(size_t bytes)
+{
+    void* p = nullptr;
+    HIP_CHECK(hipMalloc(&p, bytes ? bytes : 256));
+    allocs.push_back(p);
+    return p;
+}
+void WeightBuilder::release_staging()
+{
+    if (staging) { (void)hipStreamSynchronize(ctx.stream); (void)hipFree(staging); staging = nullptr; staging_cap = 0; }
+}
+const BoundTensor& WeightBuilder::get(const std::string& name) const
+{
+    auto it = w->find(name);
+    SDE_REQUIRE(it != w->end(), SDE_ERR_MODEL, "weight not found in ONNX graph: " + name);
+    const OnnxTensor* t = it->second.t;
+    SDE_REQUIRE(t->data_type == 1 || t->data_type == 10, SDE_ERR_MODEL, "weight " + name + " is neither f32 nor f16");
+    return it->second;
+}
+std::vector<float> WeightBuilder::host_f32(const std::string& name) const
+{
+    const BoundTensor& b = get(name);
+    const int64_t n = b.t->numel();
+    std::vector<float> v((size_t)n);
+    if (b.t->data_type == 1) memcpy(v.data(), b.t->data, (size_t)n * 4);
+    else { const half_t* h = (const half_t*)b.t->data; for (int64_t i = 0; i < n; ++i) v[(size_t)i] = (float)h[i]; }
+    return v;
+}
+float* WeightBuilder::upload_f32(const std::vector<float>& v)
+{
+    float* d = (float*)dmalloc(v.size() * 4);
+    HIP_CHECK(hipMemcpy(d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return d;
+}
+DevNorm WeightBuilder::norm(const std::string& prefix)
+{
+    DevNorm n;
+    std::vector<float> g = host_f32(prefix + ".weight"), b = host_f32(prefix + ".bias");
+    SDE_REQUIRE(g.size() == b.size(), SDE_ERR_MODEL, "norm " + prefix + ": gamma/beta size mismatch");
+    n.C = (int)g.size(); n.gamma = upload_f32(g); n.beta = upload_f32(b);
+    params += 2 * n.C;
+    return n;
+}
+DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std::vector<std::string>& bias_names, int cin_pad, bool geglu)
+{
+    DevLinear L;
+    int I = -1, kh = 1, kw = 1, N = 0;
+    for (auto& nm : names) {
+        const BoundTensor& b = get(nm);
+        const auto& d = b.t->dims;
+        int i, k1 = 1, k2 = 1;
+        if (d.size() == 4) { i = (int)d[1]; k1 = (int)d[2]; k2 = (int)d[3]; N += (int)d[0]; }
+        else { SDE_REQUIRE(d.size() == 2, SDE_ERR_MODEL, "weight " + nm + " has unsupported rank"); i = (int)b.in_dim(); N += (int)b.out_dim(); }
+        if (I < 0) { I = i; kh = k1; kw = k2; }
+        SDE_REQUIRE(I == i && kh == k1 && kw == k2, SDE_ERR_MODEL, "cannot stack " + nm + ": inner shape differs");
+    }
+    SDE_REQUIRE(kh == kw && (kh == 1 || kh == 3), SDE_ERR_MODEL, "only 1x1 and 3x3 kernels are supported: " + names[0]);
+    const int Ipad = cin_pad > 0 ? cin_pad : I;
+    SDE_REQUIRE(Ipad >= I, SDE_ERR_MODEL, "cin_pad smaller than Cin for " + names[0]);
+    L.taps = kh * kw; L.Cin = Ipad; L.K = L.taps * Ipad; L.N = N; L.Npad = gemm_npad(N); L.geglu = geglu;
+    const size_t wbytes = (size_t)L.Npad * L.K * sizeof(half_t);
+    L.W = (half_t*)dmalloc(wbytes);
+    HIP_CHECK(hipMemsetAsync(L.W, 0, wbytes, ctx.stream));
+    int row0 = 0;
+    for (auto& nm : names) {
+        const BoundTensor& b = get(nm);
+        const size_t nbytes = (size_t)b.t->numel() * (b.t->data_type == 1 ? 4 : 2);
+        if (nbytes > staging_cap) {
+            if (staging) { HIP_CHECK(hipStreamSynchronize(ctx.stream)); HIP_CHECK(hipFree(staging)); }
+            staging_cap = std::max(nbytes, (size_t)64 << 20);
+            HIP_CHECK(hipMalloc(&staging, staging_cap));
+        }
+        HIP_CHECK(hipMemcpyAsync(staging, b.t->data, nbytes, hipMemcpyHostToDevice, ctx.stream));
+        RepackArgs r;
+        r.src = staging; r.src_is_f16 = b.t->data_type == 10;
+        r.O = (int)(b.t->dims.size() == 4 ? b.t->dims[0] : b.out_dim());
+        r.I = I; r.KH = kh; r.KW = kw; r.in_out = b.in_out ? 1 : 0;
+        r.dst = L.W; r.dst_row0 = row0; r.Ipad = Ipad; r.i0 = 0; r.Kdst = L.K;
+        r.geglu_half = geglu ? r.O / 2 : 0;
+        if (geglu) SDE_REQUIRE(names.size() == 1 && (r.O / 2) % 16 == 0, SDE_ERR_MODEL, "GEGLU projection width must be a multiple of 32");
+        launch_repack(ctx, r);
+        // the host->device copy of pageable memory may still be reading `staging` asynchronously only on the device side;
+        // both it and the repack are ordered on ctx.stream.
+        row0 += r.O;
+        params += b.t->numel();
+    }
+    if (!bias_names.empty()) {
+        std::vector<float> bias;
+        for (auto& bn : bias_names) { auto v = host_f32(bn); bias.insert(bias.end(), v.begin(), v.end()); params += (int64_t)v.size(); }
+        SDE_REQUIRE((int)bias.size() == N, SDE_ERR_MODEL, "bias size mismatch for " + names[0]);
+        L.bias = upload_f32(bias);
+    }
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------ forward helpers
+namespace {
+
+struct Act { half_t* p; int C, H, W; };  // NHWC activation [NB*H*W][C]
+
+void run_gemm(Exec& ex, GemmArgs& g)
+{
+    if (ex.dry()) return;
+    launch_gemm(ex.ctx, g);
+}
+
+// linear / 1x1 conv over rows
+void linear(Exec& ex, const DevLinear& L, const half_t* A, int lda, int M, half_t* D, int ldd, const half_t* R = nullptr, int ldr = 0,
+            const half_t* A1 = nullptr, int C0 = 0, int C1 = 0, int lda1 = 0)
+{
+    GemmArgs g;
+    g.A0 = A; g.lda0 = lda; g.C0 = A1 ? C0 : L.K; g.A1 = A1; g.C1 = A1 ? C1 : 0; g.lda1 = lda1;
+    g.M = M; g.N = L.N; g.K = L.K; g.taps = 1;
+    g.W = L.W; g.Npad = L.Npad; g.bias = L.bias; g.R = R; g.ldr = ldr; g.D = D; g.ldd = ldd;
+    g.epi = L.geglu ? EPI_GEGLU : EPI_STD;
+    SDE_REQUIRE(L.taps == 1 && g.C0 + g.C1 == L.K, SDE_ERR_MODEL, "linear: operand width mismatch");
+    run_gemm(ex, g);
+}
+
+// 3x3 conv (pad 1) over NHWC; returns output spatial size through Ho/Wo
+void conv3x3(Exec& ex, const DevLinear& L, const half_t* A, int C, int NB, int H, int W, int stride, int ups, half_t* D, int ldd,
+             const float* bias, const half_t* R, int ldr, int epi = EPI_STD, float* Df = nullptr)
+{
+    GemmArgs g;
+    g.A0 = A; g.lda0 = C; g.C0 = C;
+    g.taps = 9; g.stride = stride; g.ups = ups;
+    g.Hi = ups ? 2 * H : H; g.Wi = ups ? 2 * W : W;
+    g.Ho = (g.Hi - 1) / stride + 1; g.Wo = (g.Wi - 1) / stride + 1;
+    g.M = NB * g.Ho * g.Wo; g.N = L.N; g.K = L.K;
+    g.W = L.W; g.Npad = L.Npad; g.bias = bias; g.R = R; g.ldr = ldr; g.D = D; g.Df = Df; g.ldd = ldd; g.epi = epi;
+    SDE_REQUIRE(L.taps == 9 && L.Cin == C, SDE_ERR_MODEL, "conv3x3: channel mismatch");
+    run_gemm(ex, g);
+}
+
+void groupnorm(Exec& ex, const DevNorm& n, const half_t* X0, int C0, const half_t* X1, int C1, int NB, int HW, float eps, bool silu, half_t* Y)
+{
+    SDE_REQUIRE(n.C == C0 + C1, SDE_ERR_MODEL, "groupnorm: channel mismatch");
+    GroupNormArgs a;
+    a.X0 = X0; a.X1 = X1; a.C0 = C0; a.C1 = C1; a.NB = NB; a.HW = HW; a.groups = 32; a.eps = eps; a.gamma = n.gamma; a.beta = n.beta;
+    a.silu = silu; a.Y = Y;
+    size_t m = ex.arena->mark();
+    a.ws = ex.arena->get<float>(groupnorm_ws_floats(NB, C0 + C1, HW));
+    if (!ex.dry()) launch_groupnorm(ex.ctx, a);
+    ex.arena->release(m);  // stream-ordered reuse is safe: later kernels run after this one
+}
+
+void layernorm(Exec& ex, const DevNorm& n, const half_t* X, half_t* Y, int rows)
+{
+    if (ex.dry()) return;
+    launch_layernorm(ex.ctx, X, Y, rows, n.C, n.gamma, n.beta, 1e-5f);
+}
+
+// ResnetBlock2D: x (optionally a concat x0|x1) -> out [NB*H*W][cout]
+half_t* resnet(Exec& ex, const ResnetW& r, const half_t* x0, int c0, const half_t* x1, int c1, int NB, int H, int W, float eps,
+               const float* tbias)
+{
+    const int M = NB * H * W, cin = c0 + c1;
+    SDE_REQUIRE(cin == r.cin, SDE_ERR_MODEL, "resnet: input channel mismatch");
+    half_t* out = ex.arena->get<half_t>((size_t)M * r.cout);
+    const size_t mk = ex.arena->mark();
+    half_t* hn = ex.arena->get<half_t>((size_t)M * cin);
+    groupnorm(ex, r.n1, x0, c0, x1, c1, NB, H * W, eps, true, hn);
+    half_t* h1 = ex.arena->get<half_t>((size_t)M * r.cout);
+    conv3x3(ex, r.conv1, hn, cin, NB, H, W, 1, 0, h1, r.cout, r.has_temb ? tbias + r.temb_off : r.conv1.bias, nullptr, 0);
+    half_t* hn2 = ex.arena->get<half_t>((size_t)M * r.cout);
+    groupnorm(ex, r.n2, h1, r.cout, nullptr, 0, NB, H * W, eps, true, hn2);
+    const half_t* sc = x0;
+    if (r.has_shortcut) {
+        half_t* s = ex.arena->get<half_t>((size_t)M * r.cout);
+        linear(ex, r.shortcut, x0, c0, M, s, r.cout, nullptr, 0, x1, c0, c1, c1);
+        sc = s;
+    } else SDE_REQUIRE(x1 == nullptr && cin == r.cout, SDE_ERR_MODEL, "resnet: identity shortcut with changing width");
+    conv3x3(ex, r.conv2, hn2, r.cout, NB, H, W, 1, 0, out, r.cout, r.conv2.bias, sc, r.cout);
+    ex.arena->release(mk);
+    return out;
+}
+
+void attention(Exec& ex, const half_t* Q, int ldq, const half_t* K, int ldk, const half_t* V, int ldv, half_t* O, int ldo, int NB,
+               int heads, int Sq, int Skv, int d)
+{
+    if (ex.dry()) return;
+    AttnArgs a;
+    a.Q = Q; a.K = K; a.V = V; a.O = O; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.NB = NB; a.heads = heads; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.0f / sqrtf((float)d);
+    launch_attention(ex.ctx, a);
+}
+
+// Transformer2DModel (depth 1) on NHWC tokens; conv 1x1 and Linear projections are the same contraction here.
+half_t* transformer(Exec& ex, const TransformerW& t, const half_t* x, int NB, int H, int W, const half_t* kv, int S)
+{
+    const int C = t.C, HW = H * W, M = NB * HW, d = C / t.heads;
+    half_t* out = ex.arena->get<half_t>((size_t)M * C);
+    const size_t mk = ex.arena->mark();
+    half_t* n = ex.arena->get<half_t>((size_t)M * C);
+    groupnorm(ex, t.gn, x, C, nullptr, 0, NB, HW, 1e-6f, false, n);
+    half_t* h = ex.arena->get<half_t>((size_t)M * C);
+    linear(ex, t.proj_in, n, C, M, h, C);
+    // self-attention
+    layernorm(ex, t.ln1, h, n, M);
+    half_t* qkv = ex.arena->get<half_t>((size_t)M * 3 * C);
+    linear(ex, t.qkv, n, C, M, qkv, 3 * C);
+    half_t* ao = ex.arena->get<half_t>((size_t)M * C);
+    attention(ex, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, ao, C, NB, t.heads, HW, HW, d);
+    half_t* h1 = ex.arena->get<half_t>((size_t)M * C);
+    linear(ex, t.out1, ao, C, M, h1, C, h, C);
+    // cross-attention (K/V of the text tokens come from the per-run cache)
+    layernorm(ex, t.ln2, h1, n, M);
+    half_t* q = qkv;  // reuse
+    linear(ex, t.q2, n, C, M, q, C);
+    attention(ex, q, C, kv, 2 * C, kv + C, 2 * C, ao, C, NB, t.heads, HW, S, d);
+    linear(ex, t.out2, ao, C, M, h, C, h1, C);  // h <- h1 + attn2
+    // GEGLU feed-forward
+    layernorm(ex, t.ln3, h, n, M);
+    half_t* g = ex.arena->get<half_t>((size_t)M * 4 * C);
+    linear(ex, t.ff1, n, C, M, g, 4 * C);
+    linear(ex, t.ff2, g, 4 * C, M, h1, C, h, C);  // h1 <- h + ff
+    linear(ex, t.proj_out, h1, C, M, out, C, x, C);
+    ex.arena->release(mk);
+    return out;
+}
+
+ResnetW build_resnet(WeightBuilder& b, const std::string& p, bool temb)
+{
+    ResnetW r;
+    r.n1 = b.norm(p + ".norm1");
+    r.n2 = b.norm(p + ".norm2");
+    r.has_temb = temb && b.has(p + ".time_emb_proj.weight");
+    r.conv1 = r.has_temb ? b.linear({p + ".conv1.weight"}, {}) : b.linear({p + ".conv1.weight"}, {p + ".conv1.bias"});
+    r.conv2 = b.linear({p + ".conv2.weight"}, {p + ".conv2.bias"});
+    r.cin = r.conv1.Cin; r.cout = r.conv1.N;
+    r.has_shortcut = b.has(p + ".conv_shortcut.weight");
+    if (r.has_shortcut) r.shortcut = b.linear({p + ".conv_shortcut.weight"}, {p + ".conv_shortcut.bias"});
+    SDE_REQUIRE(r.n1.C == r.cin && r.n2.C == r.cout, SDE_ERR_MODEL, "resnet " + p + ": norm width mismatch");
+    return r;
+}
+
+TransformerW build_transformer(WeightBuilder& b, const std::string& p, int heads)
+{
+    TransformerW t;
+    t.gn = b.norm(p + ".norm");
+    t.proj_in = b.linear({p + ".proj_in.weight"}, {p + ".proj_in.bias"});
+    t.proj_out = b.linear({p + ".proj_out.weight"}, {p + ".proj_out.bias"});
+    const std::string k = p + ".transformer_blocks.0";
+    t.ln1 = b.norm(k + ".norm1"); t.ln2 = b.norm(k + ".norm2"); t.ln3 = b.norm(k + ".norm3");
+    t.qkv = b.linear({k + ".attn1.to_q.weight", k + ".attn1.to_k.weight", k + ".attn1.to_v.weight"}, {});
+    t.out1 = b.linear({k + ".attn1.to_out.0.weight"}, {k + ".attn1.to_out.0.bias"});
+    t.q2 = b.linear({k + ".attn2.to_q.weight"}, {});
+    t.kv2 = b.linear({k + ".attn2.to_k.weight", k + ".attn2.to_v.weight"}, {});
+    t.out2 = b.linear({k + ".attn2.to_out.0.weight"}, {k + ".attn2.to_out.0.bias"});
+    t.ff1 = b.linear({k + ".ff.net.0.proj.weight"}, {k + ".ff.net.0.proj.bias"}, 0, true);
+    t.ff2 = b.linear({k + ".ff.net.2.weight"}, {k + ".ff.net.2.bias"});
+    t.C = t.proj_in.N; t.heads = heads;
+    SDE_REQUIRE(t.C % heads == 0, SDE_ERR_MODEL, "transformer " + p + ": width not divisible by head count");
+    SDE_REQUIRE(t.ff1.N == 8 * t.C && t.ff2.K == 4 * t.C && t.qkv.N == 3 * t.C, SDE_ERR_MODEL, "transformer " + p + ": unexpected shapes");
+    return t;
+}
+
+int count_prefix(const WeightMap& w, const std::string& fmt_a, const std::string& fmt_b)
+{
+    int n = 0;
+    while (w.count(fmt_a + std::to_string(n) + fmt_b)) ++n;
+    return n;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------ UNet
+void UNetModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b, int heads_override)
+{
+    n_levels = count_prefix(w, "down_blocks.", ".resnets.0.conv1.weight");
+    SDE_REQUIRE(n_levels >= 1 && n_levels <= 8, SDE_ERR_MODEL, "unet: cannot find down_blocks.*.resnets.0.conv1.weight");
+    layers_per_block = count_prefix(w, "down_blocks.0.resnets.", ".conv1.weight");
+    boc.clear(); down_attn.clear(); heads.clear();
+    for (int i = 0; i < n_levels; ++i) {
+        boc.push_back((int)b.get("down_blocks." + std::to_string(i) + ".resnets.0.conv1.weight").t->dims[0]);
+        down_attn.push_back(w.count("down_blocks." + std::to_string(i) + ".attentions.0.norm.weight") != 0);
+    }
+    const std::string mk = "mid_block.attentions.0.transformer_blocks.0.attn2.to_k.weight";
+    ctx_dim = (int)b.get(mk).in_dim();
+    linear_proj = b.get("mid_block.attentions.0.proj_in.weight").t->dims.size() == 2;
+    in_channels = (int)b.get("conv_in.weight").t->dims[1];
+    out_channels = (int)b.get("conv_out.weight").t->dims[0];
+    SDE_REQUIRE(in_channels <= kInPad, SDE_ERR_MODEL, "unet: too many input channels");
+    for (int i = 0; i < n_levels; ++i) {
+        int hd = 0;
+        if (heads_override > 0) { heads.push_back(heads_override); continue; }
+        std::string scope = down_attn[i] ? "/down_blocks." + std::to_string(i) + "/attentions.0/transformer_blocks.0/attn1/"
+                                         : "/mid_block/attentions.0/transformer_blocks.0/attn1/";
+        hd = onnx_attention_head_dim(m, scope);
+        if (hd <= 0 || boc[i] % hd) hd = ctx_dim == 1024 ? 64 : boc[i] / 8;  // SD2.x: d=64 ; SD1.x: 8 heads
+        heads.push_back(boc[i] / hd);
+    }
+    // stem + time embedding
+    conv_in = b.linear({"conv_in.weight"}, {"conv_in.bias"}, kInPad);
+    time_l1 = b.linear({"time_embedding.linear_1.weight"}, {"time_embedding.linear_1.bias"});
+    time_l2 = b.linear({"time_embedding.linear_2.weight"}, {"time_embedding.linear_2.bias"});
+    temb_dim = time_l1.N;
+    std::vector<ResnetW*> all_res;
+    n_transformers = 0; transformers.clear();
+    down.assign(n_levels, DownBlock());
+    for (int i = 0; i < n_levels; ++i) {
+        const std::string p = "down_blocks." + std::to_string(i);
+        for (int j = 0; j < layers_per_block; ++j) {
+            down[i].res.push_back(build_resnet(b, p + ".resnets." + std::to_string(j), true));
+            if (down_attn[i]) down[i].att.push_back(build_transformer(b, p + ".attentions." + std::to_string(j), heads[i]));
+        }
+        down[i].has_down = w.count(p + ".downsamplers.0.conv.weight") != 0;
+        if (down[i].has_down) down[i].down = b.linear({p + ".downsamplers.0.conv.weight"}, {p + ".downsamplers.0.conv.bias"});
+    }
+    mid_res0 = build_resnet(b, "mid_block.resnets.0", true);
+    mid_att = build_transformer(b, "mid_block.attentions.0", heads[n_levels - 1]);
+    mid_res1 = build_resnet(b, "mid_block.resnets.1", true);
+    up.assign(n_levels, UpBlock());
+    for (int i = 0; i < n_levels; ++i) {
+        const std::string p = "up_blocks." + std::to_string(i);
+        const int lvl = n_levels - 1 - i;
+        const bool att = w.count(p + ".attentions.0.norm.weight") != 0;
+        for (int j = 0; j < layers_per_block + 1; ++j) {
+            up[i].res.push_back(build_resnet(b, p + ".resnets." + std::to_string(j), true));
+            if (att) up[i].att.push_back(build_transformer(b, p + ".attentions." + std::to_string(j), heads[lvl]));
+        }
+        up[i].has_up = w.count(p + ".upsamplers.0.conv.weight") != 0;
+        if (up[i].has_up) up[i].up = b.linear({p + ".upsamplers.0.conv.weight"}, {p + ".upsamplers.0.conv.bias"});
+    }
+    norm_out = b.norm("conv_norm_out");
+    conv_out = b.linear({"conv_out.weight"}, {"conv_out.bias"});
+    // stable pointers now that the vectors are final
+    for (auto& d : down) { for (auto& r : d.res) all_res.push_back(&r); for (auto& t : d.att) transformers.push_back(&t); }
+    all_res.push_back(&mid_res0); transformers.push_back(&mid_att); all_res.push_back(&mid_res1);
+    for (auto& u : up) { for (auto& r : u.res) all_res.push_back(&r); for (auto& t : u.att) transformers.push_back(&t); }
+    for (size_t i = 0; i < transformers.size(); ++i) transformers[i]->kv_index = (int)i;
+    n_transformers = (int)transformers.size();
+    // all time_emb_proj layers stacked into one GEMV; its bias also carries conv1.bias
+    {
+        std::vector<std::string> names;
+        std::vector<float> bias;
+        std::vector<std::pair<ResnetW*, std::string>> order;
+        auto add = [&](ResnetW& r, const std::string& p) {
+            if (!r.has_temb) return;
+            r.temb_off = temb_total; temb_total += r.cout;
+            names.push_back(p + ".time_emb_proj.weight");
+            auto tb = b.host_f32(p + ".time_emb_proj.bias"), cb = b.host_f32(p + ".conv1.bias");
+            SDE_REQUIRE((int)tb.size() == r.cout && (int)cb.size() == r.cout, SDE_ERR_MODEL, "time_emb_proj bias size mismatch at " + p);
+            for (int k = 0; k < r.cout; ++k) bias.push_back(tb[k] + cb[k]);
+        };
+        for (int i = 0; i < n_levels; ++i)
+            for (int j = 0; j < layers_per_block; ++j) add(down[i].res[j], "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j));
+        add(mid_res0, "mid_block.resnets.0"); add(mid_res1, "mid_block.resnets.1");
+        for (int i = 0; i < n_levels; ++i)
+            for (int j = 0; j < layers_per_block + 1; ++j) add(up[i].res[j], "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j));
+        temb_all = b.linear(names, {});
+        temb_all.bias = b.upload_f32(bias);
+        b.params += (int64_t)bias.size() * 2;
+    }
+    n_params = b.params;
+}
+
+void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, float timestep, const half_t* ehs_h, int S,
+                        half_t* const* kv_cache, bool fill_kv, float* out_nchw) const
+{
+    const int div = 1 << (n_levels - 1);
+    SDE_REQUIRE(h % div == 0 && w % div == 0, SDE_ERR_INVALID_ARGUMENT,
+                "latent height/width must be divisible by " + std::to_string(div) + " (image size by " + std::to_string(8 * div) + ")");
+    Arena& ar = *ex.arena;
+    const float eps = 1e-5f;
+    // 1. time embedding: timestep is cast to int64 inside the exported graph (sd2pyke.py:121) => truncation
+    const float tt = truncf(timestep);
+    float* temb = ar.get<float>(boc[0]);
+    float* e1 = ar.get<float>(temb_dim);
+    float* emb = ar.get<float>(temb_dim);
+    float* tbias = ar.get<float>(temb_total);
+    if (!ex.dry()) {
+        launch_timestep_embedding(ex.ctx, tt, temb, boc[0]);
+        launch_gemv(ex.ctx, time_l1.W, temb, time_l1.bias, e1, time_l1.N, time_l1.K, false, true);
+        launch_gemv(ex.ctx, time_l2.W, e1, time_l2.bias, emb, time_l2.N, time_l2.K, false, false);
+        launch_gemv(ex.ctx, temb_all.W, emb, temb_all.bias, tbias, temb_all.N, temb_all.K, true, false);
+    }
+    // 2. text K/V projections (constant over the denoise loop)
+    if (fill_kv)
+        for (int i = 0; i < n_transformers; ++i)
+            linear(ex, transformers[i]->kv2, ehs_h, ctx_dim, N * S, kv_cache[i], 2 * transformers[i]->C);
+    // 3. encoder
+    struct Skip { half_t* p; int C, H, W; };
+    std::vector<Skip> skips;
+    int H = h, W = w;
+    half_t* cur = ar.get<half_t>((size_t)N * H * W * boc[0]);
+    conv3x3(ex, conv_in, x_packed, kInPad, N, H, W, 1, 0, cur, boc[0], conv_in.bias, nullptr, 0);
+    int C = boc[0];
+    skips.push_back({cur, C, H, W});
+    for (int i = 0; i < n_levels; ++i) {
+        for (int j = 0; j < layers_per_block; ++j) {
+            cur = resnet(ex, down[i].res[j], cur, C, nullptr, 0, N, H, W, eps, tbias);
+            C = down[i].res[j].cout;
+            if (!down[i].att.empty()) cur = transformer(ex, down[i].att[j], cur, N, H, W, kv_cache[down[i].att[j].kv_index], S);
+            skips.push_back({cur, C, H, W});
+        }
+        if (down[i].has_down) {
+            const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+            half_t* d = ar.get<half_t>((size_t)N * Ho * Wo * C);
+            conv3x3(ex, down[i].down, cur, C, N, H, W, 2, 0, d, C, down[i].down.bias, nullptr, 0);
+            cur = d; H = Ho; W = Wo;
+            skips.push_back({cur, C, H, W});
+        }
+    }
+    // 4. middle
+    cur = resnet(ex, mid_res0, cur, C, nullptr, 0, N, H, W, eps, tbias);
+    cur = transformer(ex, mid_att, cur, N, H, W, kv_cache[mid_att.kv_index], S);
+    cur = resnet(ex, mid_res1, cur, C, nullptr, 0, N, H, W, eps, tbias);
+    // 5. decoder: cat([hidden, skip]) — hidden first
+    for (int i = 0; i < n_levels; ++i) {
+        for (int j = 0; j < layers_per_block + 1; ++j) {
+            SDE_REQUIRE(!skips.empty(), SDE_ERR_MODEL, "unet: skip stack underflow");
+            Skip s = skips.back(); skips.pop_back();
+            SDE_REQUIRE(s.H == H && s.W == W, SDE_ERR_MODEL, "unet: skip connection size mismatch");
+            cur = resnet(ex, up[i].res[j], cur, C, s.p, s.C, N, H, W, eps, tbias);
+            C = up[i].res[j].cout;
+            if (!up[i].att.empty()) cur = transformer(ex, up[i].att[j], cur, N, H, W, kv_cache[up[i].att[j].kv_index], S);
+        }
+        if (up[i].has_up) {
+            half_t* u = ar.get<half_t>((size_t)N * 4 * H * W * C);
+            conv3x3(ex, up[i].up, cur, C, N, H, W, 1, 1, u, C, up[i].up.bias, nullptr, 0);
+            cur = u; H *= 2; W *= 2;
+        }
+    }
+    // 6. head
+    half_t* hn = ar.get<half_t>((size_t)N * H * W * C);
+    groupnorm(ex, norm_out, cur, C, nullptr, 0, N, H * W, eps, true, hn);
+    conv3x3(ex, conv_out, hn, C, N, H, W, 1, 0, nullptr, 0, conv_out.bias, nullptr, 0, EPI_NCHW_F32, out_nchw);
+}
+
+// ------------------------------------------------------------------------------------------ VAE decoder
+void VaeDecoderModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b)
+{
+    (void)m;
+    n_levels = count_prefix(w, "decoder.up_blocks.", ".resnets.0.conv1.weight");
+    SDE_REQUIRE(n_levels >= 1 && n_levels <= 8, SDE_ERR_MODEL, "vae: cannot find decoder.up_blocks.*.resnets.0.conv1.weight");
+    const int nres = count_prefix(w, "decoder.up_blocks.0.resnets.", ".conv1.weight");
+    layers_per_block = nres - 1;
+    latent_channels = (int)b.get("post_quant_conv.weight").t->dims[0];
+    out_channels = (int)b.get("decoder.conv_out.weight").t->dims[0];
+    SDE_REQUIRE(latent_channels <= kInPad, SDE_ERR_MODEL, "vae: too many latent channels");
+    post_quant = b.linear({"post_quant_conv.weight"}, {"post_quant_conv.bias"}, kInPad);
+    conv_in = b.linear({"decoder.conv_in.weight"}, {"decoder.conv_in.bias"}, kInPad);
+    mid_res0 = build_resnet(b, "decoder.mid_block.resnets.0", false);
+    const std::string a = "decoder.mid_block.attentions.0";
+    mid_att.gn = b.norm(a + ".group_norm");
+    mid_att.q = b.linear({a + ".query.weight"}, {a + ".query.bias"});
+    mid_att.k = b.linear({a + ".key.weight"}, {a + ".key.bias"});
+    mid_att.v = b.linear({a + ".value.weight"}, {a + ".value.bias"});
+    mid_att.qkv = b.linear({a + ".query.weight", a + ".key.weight", a + ".value.weight"}, {a + ".query.bias", a + ".key.bias", a + ".value.bias"});
+    mid_att.proj = b.linear({a + ".proj_attn.weight"}, {a + ".proj_attn.bias"});
+    mid_att.C = mid_att.q.N;
+    mid_res1 = build_resnet(b, "decoder.mid_block.resnets.1", false);
+    up.assign(n_levels, UpBlock());
+    boc.clear();
+    for (int i = 0; i < n_levels; ++i) {
+        const std::string p = "decoder.up_blocks." + std::to_string(i);
+        for (int j = 0; j < nres; ++j) up[i].res.push_back(build_resnet(b, p + ".resnets." + std::to_string(j), false));
+        boc.push_back(up[i].res[0].cout);
+        up[i].has_up = w.count(p + ".upsamplers.0.conv.weight") != 0;
+        if (up[i].has_up) up[i].up = b.linear({p + ".upsamplers.0.conv.weight"}, {p + ".upsamplers.0.conv.bias"});
+    }
+    norm_out = b.norm("decoder.conv_norm_out");
+    conv_out = b.linear({"decoder.conv_out.weight"}, {"decoder.conv_out.bias"});
+    n_params = b.params;
+}
+
+void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, int w, int epi, float* out) const
+{
+    Arena& ar = *ex.arena;
+    const float eps = 1e-6f;
+    int H = h, W = w;
+    const int M0 = B * H * W;
+    // post_quant_conv (1x1) writes into a zero-padded 64-channel buffer so conv_in can read 64-wide K chunks
+    half_t* z = ar.get<half_t>((size_t)M0 * kInPad);
+    if (!ex.dry()) HIP_CHECK(hipMemsetAsync(z, 0, (size_t)M0 * kInPad * sizeof(half_t), ex.ctx.stream));
+    linear(ex, post_quant, x_packed, kInPad, M0, z, kInPad);
+    int C = conv_in.N;
+    half_t* cur = ar.get<half_t>((size_t)M0 * C);
+    conv3x3(ex, conv_in, z, kInPad, B, H, W, 1, 0, cur, C, conv_in.bias, nullptr, 0);
+    cur = resnet(ex, mid_res0, cur, C, nullptr, 0, B, H, W, eps, nullptr);
+    {   // AttentionBlock: single head over H*W tokens
+        const int S = H * W, M = B * S;
+        half_t* o = ar.get<half_t>((size_t)M * C);
+        const size_t mk = ar.mark();
+        half_t* n = ar.get<half_t>((size_t)M * C);
+        groupnorm(ex, mid_att.gn, cur, C, nullptr, 0, B, S, eps, false, n);
+        half_t* ao = ar.get<half_t>((size_t)M * C);
+        if (C <= 160 && C % 8 == 0) {
+            half_t* qkv = ar.get<half_t>((size_t)M * 3 * C);
+            linear(ex, mid_att.qkv, n, C, M, qkv, 3 * C);
+            attention(ex, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, ao, C, B, 1, S, S, C);
+        } else {
+            // wide single head (C = 512): scores via batched GEMMs + row softmax (34 GFLOP / 512^2 image, 1.4 % of the decoder)
+            SDE_REQUIRE(S % 8 == 0, SDE_ERR_INVALID_ARGUMENT, "vae attention: h*w must be a multiple of 8");
+            const int Spad = gemm_npad(S);
+            half_t* q = ar.get<half_t>((size_t)M * C);
+            half_t* k = ar.get<half_t>((size_t)B * Spad * C);
+            half_t* vT = ar.get<half_t>((size_t)B * gemm_npad(C) * S);
+            half_t* sc = ar.get<half_t>((size_t)B * S * S);
+            if (!ex.dry() && Spad != S) HIP_CHECK(hipMemsetAsync(k, 0, (size_t)B * Spad * C * sizeof(half_t), ex.ctx.stream));
+            if (!ex.dry() && gemm_npad(C) != C) HIP_CHECK(hipMemsetAsync(vT, 0, (size_t)B * gemm_npad(C) * S * sizeof(half_t), ex.ctx.stream));
+            linear(ex, mid_att.q, n, C, M, q, C);
+            for (int bi = 0; bi < B; ++bi) {   // K rows are laid out per image with Spad rows so they can serve as a GEMM "W"
+                linear(ex, mid_att.k, n + (size_t)bi * S * C, C, S, k + (size_t)bi * Spad * C, C);
+                GemmArgs g;   // V^T[c][s]
+                g.A0 = n + (size_t)bi * S * C; g.lda0 = C; g.C0 = C; g.M = S; g.N = C; g.K = C; g.taps = 1;
+                g.W = mid_att.v.W; g.Npad = mid_att.v.Npad; g.bias = mid_att.v.bias; g.D = vT + (size_t)bi * gemm_npad(C) * S; g.ldd = S;
+                g.epi = EPI_TRANS;
+                run_gemm(ex, g);
+            }
+            {
+                GemmArgs g;   // scores[b] = q[b] k[b]^T / sqrt(C)
+                g.A0 = q; g.lda0 = C; g.C0 = C; g.M = S; g.N = S; g.K = C; g.taps = 1;
+                g.W = k; g.Npad = Spad; g.D = sc; g.ldd = S; g.alpha = 1.0f / sqrtf((float)C);
+                g.batch = B; g.sA = (long long)S * C; g.sW = (long long)Spad * C; g.sD = (long long)S * S;
+                run_gemm(ex, g);
+            }
+            if (!ex.dry()) launch_softmax_rows(ex.ctx, sc, (int64_t)B * S, S);
+            {
+                GemmArgs g;   // ao[b] = P[b] V[b]
+                g.A0 = sc; g.lda0 = S; g.C0 = S; g.M = S; g.N = C; g.K = S; g.taps = 1;
+                g.W = vT; g.Npad = gemm_npad(C); g.D = ao; g.ldd = C;
+                g.batch = B; g.sA = (long long)S * S; g.sW = (long long)gemm_npad(C) * S; g.sD = (long long)S * C;
+                run_gemm(ex, g);
+            }
+        }
+        linear(ex, mid_att.proj, ao, C, M, o, C, cur, C);
+        ar.release(mk);
+        cur = o;
+    }
+    cur = resnet(ex, mid_res1, cur, C, nullptr, 0, B, H, W, eps, nullptr);
+    for (int i = 0; i < n_levels; ++i) {
+        for (auto& r : up[i].res) { cur = resnet(ex, r, cur, C, nullptr, 0, B, H, W, eps, nullptr); C = r.cout; }
+        if (up[i].has_up) {
+            half_t* u = ar.get<half_t>((size_t)B * 4 * H * W * C);
+            conv3x3(ex, up[i].up, cur, C, B, H, W, 1, 1, u, C, up[i].up.bias, nullptr, 0);
+            cur = u; H *= 2; W *= 2;
+        }
+    }
+    half_t* hn = ar.get<half_t>((size_t)B * H * W * C);
+    groupnorm(ex, norm_out, cur, C, nullptr, 0, B, H * W, eps, true, hn);
+    conv3x3(ex, conv_out, hn, C, B, H, W, 1, 0, nullptr, 0, conv_out.bias, nullptr, 0, epi, out);
+}

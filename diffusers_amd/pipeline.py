@@ -1,0 +1,287 @@
+"""Host mirror of the reference's pipeline API for the txt2img hot path:
+
+  ``StableDiffusionPipeline::new`` / ``decode_latents`` / ``approximate_decode_latents``
+      (/root/reference/src/pipelines/stable_diffusion/impl_main.rs:109-181,385-413)
+  ``StableDiffusionTxt2ImgOptions`` builder + ``run``
+      (/root/reference/src/pipelines/stable_diffusion/impl_txt2img.rs:15-48,67-219,246-327)
+  ``StableDiffusionCallback`` (/root/reference/src/pipelines/stable_diffusion/mod.rs:41-86)
+
+The CLIP text encoder stays with the caller (it runs once per prompt on the reference's ORT path), so
+``run`` takes the text embeddings ``encode_prompt`` would produce: f32 [2B,S,D] with the unconditional
+half FIRST when guidance_scale > 1 (impl_main.rs:366-370), else [B,S,D].
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import _lib
+from .schedulers import DiffusionScheduler
+
+
+@dataclass
+class StableDiffusionOptions:
+    """pipelines/stable_diffusion/mod.rs:35-38 — here the only device choice is the MI355X ordinal."""
+    device_id: int = 0
+    force_naive: bool = False
+    num_heads_override: int = 0
+
+
+class StableDiffusionPipeline:
+    def __init__(self, root: str, options: Optional[StableDiffusionOptions] = None, *, unet_onnx: Optional[str] = None,
+                 vae_decoder_onnx: Optional[str] = None, load_unet: bool = True, load_vae: bool = True):
+        L = _lib.lib()
+        options = options or StableDiffusionOptions()
+        o = _lib.EngineOpts()
+        L.sde_engine_opts_default(C.byref(o))
+        o.device_id = options.device_id
+        o.force_naive = int(options.force_naive)
+        o.num_heads_override = options.num_heads_override
+        o.load_unet, o.load_vae = int(load_unet), int(load_vae)
+        h = C.c_void_p()
+        if root is not None:
+            _lib.check(L.sde_engine_create(root.encode(), C.byref(o), C.byref(h)))
+        else:
+            _lib.check(L.sde_engine_create_from_files(unet_onnx.encode() if unet_onnx else None,
+                                                      vae_decoder_onnx.encode() if vae_decoder_onnx else None, C.byref(o), C.byref(h)))
+        self._h = h
+        self.options = options
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().sde_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def info(self) -> _lib.ModelInfo:
+        mi = _lib.ModelInfo()
+        _lib.check(_lib.lib().sde_engine_info(self._h, C.byref(mi)))
+        return mi
+
+    # --- the two ORT calls of the hot path
+    def unet(self, sample, timestep: float, encoder_hidden_states) -> np.ndarray:
+        """session.unet.run([sample, timestep, encoder_hidden_states]) (impl_txt2img.rs:283)."""
+        x = np.ascontiguousarray(sample, np.float32)
+        e = np.ascontiguousarray(encoder_hidden_states, np.float32)
+        N, _, h, w = x.shape
+        out = np.empty((N, self.info().out_channels, h, w), np.float32)
+        _lib.check(_lib.lib().sde_unet_forward(self._h, x.ctypes.data, N, h, w, float(timestep), e.ctypes.data, e.shape[1], e.shape[2],
+                                               out.ctypes.data))
+        return out
+
+    def vae_decoder(self, latent_sample) -> np.ndarray:
+        """vae_decoder.run([latent_sample]) (impl_main.rs:403): f32 [B,3,8h,8w], no post-processing."""
+        z = np.ascontiguousarray(latent_sample, np.float32)
+        B, _, h, w = z.shape
+        mi = self.info()
+        up = 1 << (mi.vae_n_levels - 1)
+        out = np.empty((B, mi.vae_out_channels, h * up, w * up), np.float32)
+        _lib.check(_lib.lib().sde_vae_decoder_run(self._h, z.ctypes.data, B, h, w, out.ctypes.data))
+        return out
+
+    def decode_latents(self, latents) -> np.ndarray:
+        """impl_main.rs:398-413 → f32 [B,H,W,3] in [0,1] (the Rgb32F image buffers)."""
+        z = np.ascontiguousarray(latents, np.float32)
+        B, _, h, w = z.shape
+        mi = self.info()
+        up = 1 << (mi.vae_n_levels - 1)
+        out = np.empty((B, h * up, w * up, mi.vae_out_channels), np.float32)
+        _lib.check(_lib.lib().sde_vae_decode(self._h, z.ctypes.data, B, h, w, out.ctypes.data))
+        return out
+
+    def approximate_decode_latents(self, latents) -> np.ndarray:
+        """impl_main.rs:385-395."""
+        z = np.ascontiguousarray(latents, np.float32)
+        B, _, h, w = z.shape
+        out = np.empty((B, h, w, 3), np.float32)
+        _lib.check(_lib.lib().sde_approximate_decode(self._h, z.ctypes.data, B, h, w, out.ctypes.data))
+        return out
+
+    # --- measurement hooks
+    def profile(self, enable: bool):
+        _lib.check(_lib.lib().sde_profile_enable(self._h, int(enable)))
+
+    def profile_reset(self):
+        _lib.check(_lib.lib().sde_profile_reset(self._h))
+
+    def profile_get(self) -> List[dict]:
+        L = _lib.lib()
+        n = C.c_int()
+        arr = (_lib.KernelStat * 64)()
+        _lib.check(L.sde_profile_get(self._h, arr, 64, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
+                     flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(min(n.value, 64))]
+
+
+CB_NONE, CB_PROGRESS, CB_LATENTS, CB_DECODED, CB_APPROXIMATE = range(5)
+
+
+@dataclass
+class Txt2ImgResult:
+    images: Optional[np.ndarray]           # f32 [B,H,W,3] in [0,1]
+    unet_calls: int = 0
+    total_ms: float = 0.0
+    unet_ms: float = 0.0
+    vae_ms: float = 0.0
+    noise_pred: Optional[np.ndarray] = None  # [n_steps,B,4,h,w] when trace=True
+    latents: Optional[np.ndarray] = None     # [n_steps,B,4,h,w] when trace=True
+    final_latents: Optional[np.ndarray] = None
+
+
+@dataclass
+class StableDiffusionTxt2ImgOptions:
+    """Fields and defaults of impl_txt2img.rs:15-65.  ``positive_prompt``/``negative_prompt`` are replaced by the
+    embeddings they encode to (``text_embeddings``) plus ``batch_size``."""
+    height: int = 512
+    width: int = 512
+    guidance_scale: float = 7.5
+    rescale_cfg: Optional[float] = None
+    steps: int = 25
+    seed: Optional[int] = None
+    ensd: int = 0  # never read by the reference's run() (it uses seed + 31337, impl_txt2img.rs:267)
+    text_embeddings: Optional[np.ndarray] = None
+    batch_size: int = 1
+    callback_kind: int = CB_NONE
+    callback_frequency: int = 1
+    callback: Optional[Callable] = None
+    init_latents: Optional[np.ndarray] = None
+    step_noise: Optional[np.ndarray] = None
+
+    # builder methods (impl_txt2img.rs:67-219)
+    def with_size(self, width: int, height: int):
+        return self.with_width(width).with_height(height)
+
+    def with_width(self, width: int):
+        self.width = max(width // 8, 1) * 8
+        return self
+
+    def with_height(self, height: int):
+        self.height = max(height // 8, 1) * 8
+        return self
+
+    def with_steps(self, steps: int):
+        self.steps = steps
+        return self
+
+    def with_text_embeddings(self, ehs, batch_size: int):
+        self.text_embeddings = np.ascontiguousarray(ehs, np.float32)
+        self.batch_size = batch_size
+        return self
+
+    def with_seed(self, seed: int):
+        self.seed = seed
+        return self
+
+    def with_random_seed(self):
+        self.seed = None
+        return self
+
+    def with_guidance_scale(self, g: float):
+        self.guidance_scale = g
+        return self
+
+    def with_eta_noise_seed_delta(self, ensd: int):
+        self.ensd = ensd
+        return self
+
+    def callback_progress(self, frequency: int, cb: Callable[[int, float], bool]):
+        self.callback_kind, self.callback_frequency, self.callback = CB_PROGRESS, frequency, lambda i, t, p: cb(i, t)
+        return self
+
+    def callback_latents(self, frequency: int, cb):
+        self.callback_kind, self.callback_frequency, self.callback = CB_LATENTS, frequency, cb
+        return self
+
+    def callback_decoded(self, frequency: int, cb):
+        self.callback_kind, self.callback_frequency, self.callback = CB_DECODED, frequency, cb
+        return self
+
+    def callback_approximate(self, frequency: int, cb):
+        self.callback_kind, self.callback_frequency, self.callback = CB_APPROXIMATE, frequency, cb
+        return self
+
+    def run(self, session: StableDiffusionPipeline, scheduler: DiffusionScheduler, *, trace: bool = False,
+            skip_decode: bool = False, device_ptrs: Optional[dict] = None) -> Txt2ImgResult:
+        """impl_txt2img.rs:246-327.  ``device_ptrs`` (bench path) = dict(ehs=, init_latents=, step_noise=, images=)
+        of raw device addresses; then nothing crosses PCIe inside the call."""
+        L = _lib.lib()
+        o = _lib.Txt2ImgOpts()
+        L.sde_txt2img_opts_default(C.byref(o))
+        o.height, o.width, o.guidance_scale, o.steps = self.height, self.width, self.guidance_scale, self.steps
+        if self.rescale_cfg is not None:
+            o.has_rescale_cfg, o.rescale_cfg = 1, self.rescale_cfg
+        if self.seed is not None:
+            o.has_seed, o.seed = 1, self.seed
+        B = self.batch_size
+        o.batch_size = B
+        h, w = self.height // 8, self.width // 8
+        keep = []
+        if device_ptrs is not None:
+            o.buffers_on_device = 1
+            o.ehs = device_ptrs["ehs"]
+            o.S, o.D = device_ptrs["S"], device_ptrs["D"]
+            o.init_latents = device_ptrs.get("init_latents")
+            o.step_noise = device_ptrs.get("step_noise")
+            images_ptr = device_ptrs.get("images")
+            images = None
+        else:
+            if self.text_embeddings is None:
+                raise ValueError("text_embeddings are required (CLIP stays on the caller's side)")
+            ehs = np.ascontiguousarray(self.text_embeddings, np.float32)
+            N = 2 * B if self.guidance_scale > 1.0 else B
+            if ehs.ndim != 3 or ehs.shape[0] != N:
+                raise ValueError(f"text_embeddings must be [{N},S,D] (uncond first under CFG), got {ehs.shape}")
+            keep.append(ehs)
+            o.ehs, o.S, o.D = ehs.ctypes.data, ehs.shape[1], ehs.shape[2]
+            if self.init_latents is not None:
+                il = np.ascontiguousarray(self.init_latents, np.float32)
+                assert il.shape == (B, 4, h, w), il.shape
+                keep.append(il)
+                o.init_latents = il.ctypes.data
+            if self.step_noise is not None:
+                sn = np.ascontiguousarray(self.step_noise, np.float32)
+                keep.append(sn)
+                o.step_noise = sn.ctypes.data
+            images = None if skip_decode else np.empty((B, self.height, self.width, 3), np.float32)
+            images_ptr = images.ctypes.data if images is not None else None
+        o.skip_decode = int(skip_decode)
+        res = Txt2ImgResult(images=images)
+        if self.callback is not None and self.callback_kind != CB_NONE:
+            kind = self.callback_kind
+            user_cb = self.callback
+
+            def tramp(step, t, payload, n, _user):
+                arr = None
+                if payload and n:
+                    arr = np.ctypeslib.as_array(payload, shape=(n,)).copy()
+                    if kind == CB_LATENTS:
+                        arr = arr.reshape(B, 4, h, w)
+                    elif kind == CB_DECODED:
+                        arr = arr.reshape(B, self.height, self.width, 3)
+                    elif kind == CB_APPROXIMATE:
+                        arr = arr.reshape(B, h, w, 3)
+                return 1 if user_cb(step, t, arr) else 0
+
+            cfn = _lib.CALLBACK(tramp)
+            keep.append(cfn)
+            o.callback, o.callback_kind, o.callback_frequency = cfn, kind, self.callback_frequency
+        if trace and device_ptrs is None:
+            # upper bound on the number of UNet calls: timesteps are set inside run(); size generously
+            nmax = self.steps + 2
+            res.noise_pred = np.zeros((nmax, B, 4, h, w), np.float32)
+            res.latents = np.zeros((nmax, B, 4, h, w), np.float32)
+            res.final_latents = np.zeros((B, 4, h, w), np.float32)
+            o.noise_pred_out, o.latents_out, o.final_latents_out = (res.noise_pred.ctypes.data, res.latents.ctypes.data,
+                                                                    res.final_latents.ctypes.data)
+        st = _lib.RunStats()
+        _lib.check(L.sde_txt2img_run(session._h, scheduler._h, C.byref(o), images_ptr, C.byref(st)))
+        res.unet_calls, res.total_ms, res.unet_ms, res.vae_ms = st.unet_calls, st.total_ms, st.unet_ms, st.vae_ms
+        if trace and res.noise_pred is not None:
+            res.noise_pred = res.noise_pred[:st.unet_calls]
+            res.latents = res.latents[:st.unet_calls]
+        return res

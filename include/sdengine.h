@@ -1,0 +1,211 @@
+/* sdengine.h — C ABI of the MI355X-native Stable Diffusion denoising engine.
+ *
+ * Drop-in boundary for the hot path of pyke Diffusers (reference paths are relative to the
+ * reference repository root).  A Rust `-sys` crate (or any FFI) binds exactly these entry points;
+ * INTEGRATION.md shows the reference-side stub.  Conventions:
+ *   - plain C types only; every tensor argument is a caller-owned buffer of f32, row-major,
+ *     NCHW unless stated otherwise — the same layout the reference hands to `ort::Session::run`;
+ *   - `*_dev` variants take DEVICE pointers (hipMalloc'd / torch CUDA tensors) instead of host ones;
+ *   - every function returns sde_status; on failure `sde_last_error()` (thread-local) explains;
+ *     nothing aborts or throws across the boundary (the reference returns anyhow::Error or panics);
+ *   - handles are opaque, owned by the library, released only by the matching *_destroy.
+ */
+#ifndef SDENGINE_H
+#define SDENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sde_status {
+    SDE_OK = 0,
+    SDE_ERR_INVALID_ARGUMENT = 1, /* bad sizes / null pointers (reference: anyhow::bail, impl_txt2img.rs:251-253) */
+    SDE_ERR_IO = 2,               /* model directory / file problems (reference: `?` on fs/ORT load, impl_main.rs:111,136-157) */
+    SDE_ERR_CONFIG = 3,           /* pyke-diffusers.toml problems, "bad framework" (impl_main.rs:113-122) */
+    SDE_ERR_MODEL = 4,            /* ONNX parse / weight-binding failure */
+    SDE_ERR_DEVICE = 5,           /* HIP runtime error, no GPU, extension built for another arch */
+    SDE_ERR_SCHEDULER = 6,        /* scheduler misuse that panics in the reference (euler_discrete.rs:140,181) */
+    SDE_ERR_CANCELLED = 7         /* a callback returned 0 (reference: `break`, impl_txt2img.rs:319-321) */
+} sde_status;
+
+typedef struct sde_engine sde_engine;
+typedef struct sde_scheduler sde_scheduler;
+
+/* Library ---------------------------------------------------------------------------------- */
+const char* sde_last_error(void);
+const char* sde_version(void);
+/* Number of visible HIP devices (0 when none / no driver).  Never fails. */
+int sde_device_count(void);
+
+/* Engine (replaces the `unet: Session` and `vae_decoder: Session` fields, impl_main.rs:59,64) - */
+typedef enum sde_dtype { SDE_F16 = 0, SDE_BF16 = 1, SDE_F32 = 2 } sde_dtype;
+
+typedef struct sde_engine_opts {
+    int device_id;       /* HIP device ordinal (the new "native MI355X(device_id)" DiffusionDevice, lib.rs:81-107) */
+    int dtype;           /* sde_dtype: activation/weight storage inside the engine; I/O is always f32 */
+    int force_naive;     /* 1 = run every contraction on the plain (non-MFMA) kernels (debug / cross-check) */
+    int load_unet;       /* 0 skips unet.onnx  (engine then only serves sde_vae_decode) */
+    int load_vae;        /* 0 skips vae_decoder.onnx */
+    int num_heads_override; /* >0 forces the attention head count when the graph does not reveal it */
+} sde_engine_opts;
+
+void sde_engine_opts_default(sde_engine_opts* opts);
+
+/* StableDiffusionPipeline::new (impl_main.rs:109-181): parse <model_dir>/pyke-diffusers.toml
+ * (config.rs:17-117), load [unet].path and [vae].decoder, upload weights. */
+sde_status sde_engine_create(const char* model_dir, const sde_engine_opts* opts, sde_engine** out);
+/* replace_unet / replace_vae (impl_main.rs:271-276,306-324): load single ONNX files. */
+sde_status sde_engine_create_from_files(const char* unet_onnx, const char* vae_decoder_onnx,
+                                        const sde_engine_opts* opts, sde_engine** out);
+void sde_engine_destroy(sde_engine* e);
+
+/* Introspection of what the loader inferred from the graphs. */
+typedef struct sde_model_info {
+    int unet_loaded, vae_loaded;
+    int in_channels, out_channels, n_levels, layers_per_block, cross_attention_dim, use_linear_projection;
+    int block_out_channels[8];
+    int num_heads[8];
+    int down_attn[8];
+    int vae_n_levels, vae_layers_per_block, vae_latent_channels, vae_out_channels;
+    int vae_block_out_channels[8];
+    int64_t unet_params, vae_params;
+} sde_model_info;
+sde_status sde_engine_info(const sde_engine* e, sde_model_info* info);
+
+/* The ORT call `unet.run([sample, timestep, encoder_hidden_states]) -> out_sample`
+ * (impl_txt2img.rs:283; I/O names and dtypes sd2pyke.py:113-125,294-295).
+ *   sample f32 [N,4,h,w]; timestep: one f32, cast to int64 inside the graph (= truncation,
+ *   sd2pyke.py:121); ehs f32 [N,S,D]; out f32 [N,4,h,w]. */
+sde_status sde_unet_forward(sde_engine* e, const float* sample, int N, int h, int w, float timestep,
+                            const float* ehs, int S, int D, float* out);
+sde_status sde_unet_forward_dev(sde_engine* e, const float* d_sample, int N, int h, int w, float timestep,
+                                const float* d_ehs, int S, int D, float* d_out);
+
+/* All of `decode_latents` (impl_main.rs:398-413) + `to_image` (:377-382): latents f32 [B,4,h,w]
+ * -> *1/0.18215 -> VAE decoder -> NHWC, /2+0.5, clamp[0,1] -> images f32 [B,8h,8w,3]. */
+sde_status sde_vae_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images_nhwc);
+sde_status sde_vae_decode_dev(sde_engine* e, const float* d_latents, int B, int h, int w, float* d_images_nhwc);
+/* The bare ORT call `vae_decoder.run([latent_sample]) -> sample` (impl_main.rs:403): f32 [B,3,8h,8w], NCHW, no post-processing. */
+sde_status sde_vae_decoder_run(sde_engine* e, const float* latent_sample, int B, int h, int w, float* sample_nchw);
+/* `approximate_decode_latents` (impl_main.rs:385-395): 4->3 channel linear map + clamp -> f32 [B,h,w,3]. */
+sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images_nhwc);
+
+/* Schedulers (trait DiffusionScheduler, schedulers/mod.rs:154-192) -------------------------- */
+typedef enum sde_scheduler_kind {
+    SDE_SCHED_EULER = 0,   /* euler_discrete.rs */
+    SDE_SCHED_EULER_A = 1, /* euler_ancestral_discrete.rs */
+    SDE_SCHED_DPMPP = 2,   /* dpm_solver_multistep.rs (DPM-Solver++ multistep) */
+    SDE_SCHED_DDIM = 3,    /* ddim.rs */
+    SDE_SCHED_DDPM = 4,    /* ddpm.rs */
+    SDE_SCHED_LMS = 5      /* not in the reference (README.md:35 only); k-diffusion definition */
+} sde_scheduler_kind;
+typedef enum sde_beta_schedule { SDE_BETA_LINEAR = 0, SDE_BETA_SCALED_LINEAR = 1, SDE_BETA_SQUAREDCOS_CAP_V2 = 2 } sde_beta_schedule;
+typedef enum sde_prediction_type { SDE_PRED_EPSILON = 0, SDE_PRED_SAMPLE = 1, SDE_PRED_V = 2 } sde_prediction_type;
+
+typedef struct sde_sched_cfg {
+    int num_train_timesteps;   /* 1000 */
+    float beta_start, beta_end;
+    int beta_schedule;         /* sde_beta_schedule */
+    int prediction_type;       /* sde_prediction_type (ignored by Euler/Euler-a/LMS: epsilon only, as in the reference) */
+    int reference_quirks;      /* 1 (default) = bug-for-bug with the reference; 0 = "fixed" variants */
+    /* DPM-Solver++ */
+    int solver_order;          /* 2 */
+    int lower_order_final;     /* 1 */
+    /* DDIM */
+    int clip_sample, set_alpha_to_one, steps_offset;
+    /* DDPM */
+    int variance_type;         /* 0 fixed_small, 1 fixed_small_log, 2 fixed_large, 3 fixed_large_log, 4 learned */
+} sde_sched_cfg;
+
+/* `stable_diffusion_v1_optimized_default()` of the given kind (euler_discrete.rs:261,
+ * dpm_solver_multistep.rs:404-419, ddim.rs:275-286, ddpm.rs:269). */
+void sde_sched_cfg_sd_v1(int kind, sde_sched_cfg* cfg);
+/* `Default::default()` of the given kind (linear 0.0001..0.02; e.g. euler_discrete.rs:41-45). */
+void sde_sched_cfg_default(int kind, sde_sched_cfg* cfg);
+
+sde_status sde_scheduler_create(int kind, const sde_sched_cfg* cfg, sde_scheduler** out);
+void sde_scheduler_destroy(sde_scheduler* s);
+int sde_scheduler_order(const sde_scheduler* s);                       /* DiffusionScheduler::order */
+int sde_scheduler_len(const sde_scheduler* s);                         /* ::len (num_train_timesteps) */
+sde_status sde_scheduler_set_timesteps(sde_scheduler* s, int num_inference_steps);
+int sde_scheduler_num_timesteps(const sde_scheduler* s);               /* timesteps().len() */
+sde_status sde_scheduler_timesteps(const sde_scheduler* s, float* out, int capacity); /* as f32 (ToPrimitive::to_f32) */
+sde_status sde_scheduler_sigmas(const sde_scheduler* s, float* out, int capacity, int* n_out); /* Euler family table */
+float sde_scheduler_init_noise_sigma(const sde_scheduler* s);
+/* Host f32 mirrors of the trait's tensor methods (n = number of elements), for callers that keep
+ * their own loop and for parity tests.  `noise` may be NULL for deterministic schedulers. */
+sde_status sde_scheduler_scale_model_input(sde_scheduler* s, const float* sample, size_t n, float timestep, float* out);
+sde_status sde_scheduler_step(sde_scheduler* s, const float* model_output, float timestep, const float* sample,
+                              const float* noise, size_t n, float* prev_sample);
+sde_status sde_scheduler_add_noise(sde_scheduler* s, const float* original, const float* noise, size_t n,
+                                   float timestep, float* out);
+
+/* txt2img (StableDiffusionTxt2ImgOptions::run, impl_txt2img.rs:246-327) --------------------- */
+typedef enum sde_callback_kind {  /* StableDiffusionCallback, pipelines/stable_diffusion/mod.rs:41-86 */
+    SDE_CB_NONE = 0, SDE_CB_PROGRESS = 1, SDE_CB_LATENTS = 2, SDE_CB_DECODED = 3, SDE_CB_APPROXIMATE = 4
+} sde_callback_kind;
+/* step index, timestep, payload (NULL / latents [B,4,h,w] / images [B,H,W,3] / images [B,h,w,3]),
+ * payload element count, user pointer.  Return 0 to stop the loop (reference: `false` -> break). */
+typedef int (*sde_callback_fn)(int step, float timestep, const float* payload, size_t payload_len, void* user);
+
+typedef struct sde_txt2img_opts {
+    int height, width;          /* must be divisible by 8 (impl_txt2img.rs:251-253) */
+    float guidance_scale;       /* CFG is on iff > 1.0 (:258) */
+    int has_rescale_cfg; float rescale_cfg; /* Option<f32> (:293-297) */
+    int steps;
+    int has_seed; uint64_t seed; /* None -> random (:248).  See DESIGN.md: RNG stream is NOT rand::StdRng-compatible. */
+    int batch_size;             /* B = positive_prompt.len() (:256) */
+    /* text embeddings from `encode_prompt` (impl_main.rs:339-375): f32 [N,S,D], N = 2B (uncond FIRST) when CFG is on, else B */
+    const float* ehs; int S, D;
+    const float* init_latents;  /* optional f32 [B,4,h,w] of N(0,1) draws replacing the seeded latents (:261-262) */
+    const float* step_noise;    /* optional f32 [n_timesteps,B,4,h,w]: the scheduler's per-step N(0,1) draws */
+    int buffers_on_device;      /* 1: ehs / init_latents / step_noise / images_out are DEVICE pointers */
+    int skip_decode;            /* 1: return final latents only (images_out untouched) */
+    int callback_kind, callback_frequency; sde_callback_fn callback; void* callback_user;
+    /* optional taps for parity tests (host pointers, may be NULL) */
+    float* noise_pred_out;      /* f32 [n_timesteps,B,4,h,w]: CFG-combined model output per step */
+    float* latents_out;         /* f32 [n_timesteps,B,4,h,w]: latents after each scheduler step */
+    float* final_latents_out;   /* f32 [B,4,h,w] */
+} sde_txt2img_opts;
+
+void sde_txt2img_opts_default(sde_txt2img_opts* o);
+
+typedef struct sde_run_stats {
+    int unet_calls; float total_ms, unet_ms, vae_ms;
+} sde_run_stats;
+
+/* Runs the whole loop on the device; `scheduler` is left in the post-run state the reference
+ * leaves it in.  images_out: f32 [B,H,W,3] in [0,1]. */
+sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* scheduler, const sde_txt2img_opts* opts,
+                           float* images_out, sde_run_stats* stats);
+
+/* Measurement hooks (bench.py) ------------------------------------------------------------- */
+typedef struct sde_kernel_stat {
+    char name[48];
+    uint64_t launches;
+    double total_ms;        /* HIP-event time summed over launches (on the engine's stream) */
+    double flops;           /* algorithmic FLOPs (2*MAC) summed over launches */
+    double bytes;           /* algorithmic bytes summed over launches */
+} sde_kernel_stat;
+/* enable=1: bracket every kernel launch with HIP events on the engine stream and accumulate per kernel class. */
+sde_status sde_profile_enable(sde_engine* e, int enable);
+sde_status sde_profile_reset(sde_engine* e);
+/* Resolves pending events and copies up to `capacity` entries; *n_out = number of classes. */
+sde_status sde_profile_get(sde_engine* e, sde_kernel_stat* out, int capacity, int* n_out);
+sde_status sde_synchronize(sde_engine* e);
+
+/* Kernel-level test hooks: run ONE contraction through the MFMA path (naive=0) or the plain path
+ * (naive=1) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32. */
+sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin,
+                         const float* w, const float* bias, int Cout, int ksize, int stride, int upsample,
+                         float* out);
+sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const float* k, const float* v,
+                              int NB, int heads, int Sq, int Skv, int d, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDENGINE_H */

@@ -1,0 +1,125 @@
+"""GPU: each hand-written MFMA kernel against (a) the plain on-device kernel and (b) a torch fp32 reference of the same
+op on the fp16-rounded operands.  Tolerance: fp16 storage + fp32 accumulation => rel-L2 <= 2e-3 (written below)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def engine(tiny_model_dir):
+    from diffusers_amd.pipeline import StableDiffusionPipeline
+    p = StableDiffusionPipeline(tiny_model_dir)
+    yield p
+    p.close()
+
+
+def run_conv(engine, naive, x, w, b, k, stride, ups):
+    from diffusers_amd import _lib
+    NB, Hi, Wi, Cin = x.shape
+    Cout = w.shape[0]
+    Hv, Wv = (2 * Hi, 2 * Wi) if ups else (Hi, Wi)
+    Ho, Wo = ((Hv - 1) // stride + 1, (Wv - 1) // stride + 1) if k == 3 else (Hv, Wv)
+    out = np.empty((NB, Ho, Wo, Cout), np.float32)
+    _lib.check(_lib.lib().sde_test_conv(engine._h, naive, x.ctypes.data, NB, Hi, Wi, Cin, w.ctypes.data,
+                                        b.ctypes.data if b is not None else None, Cout, k, stride, int(ups), out.ctypes.data))
+    return out
+
+
+CONV_CASES = [
+    # NB, H, W, Cin, Cout, k, stride, ups
+    (2, 16, 16, 64, 160, 3, 1, 0),
+    (1, 32, 32, 320, 320, 3, 1, 0),     # BM=128, BN=160
+    (2, 16, 16, 128, 128, 3, 2, 0),     # stride-2 downsample, BN=128
+    (1, 8, 8, 128, 256, 3, 1, 1),       # fused nearest-2x upsample
+    (1, 13, 11, 64, 64, 3, 1, 0),       # ragged M (not a multiple of the tile), odd spatial size
+    (1, 15, 9, 64, 64, 3, 2, 0),        # stride 2 on odd sizes
+    (3, 8, 8, 192, 320, 1, 1, 0),       # 1x1 / linear
+    (1, 64, 64, 64, 4, 3, 1, 0),        # conv_out-like: N=4 padded to one tile
+    (1, 7, 5, 24, 40, 3, 1, 0),         # unaligned channels -> plain kernel on both paths
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_mfma_vs_plain_vs_torch(engine, case):
+    NB, H, W, Cin, Cout, k, stride, ups = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    fast = run_conv(engine, 0, x, w, b, k, stride, ups)
+    plain = run_conv(engine, 1, x, w, b, k, stride, ups)
+    xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
+    if ups:
+        xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=stride if k == 3 else 1,
+                   padding=1 if k == 3 else 0).permute(0, 2, 3, 1).numpy()
+    assert fast.shape == ref.shape
+    assert rel_l2(plain, ref) < 2e-3
+    assert rel_l2(fast, ref) < 2e-3
+    assert rel_l2(fast, plain) < 2e-3
+
+
+def run_attn(engine, naive, q, k, v, heads):
+    from diffusers_amd import _lib
+    NB, Sq, Cc = q.shape
+    Skv = k.shape[1]
+    out = np.empty_like(q)
+    _lib.check(_lib.lib().sde_test_attention(engine._h, naive, q.ctypes.data, k.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv,
+                                             Cc // heads, out.ctypes.data))
+    return out
+
+
+ATTN_CASES = [
+    # NB, heads, Sq, Skv, d
+    (2, 8, 256, 256, 40),     # SD1.5 level-0 head dim
+    (1, 8, 1024, 1024, 40),
+    (2, 8, 256, 77, 40),      # cross attention, ragged key count
+    (1, 8, 64, 64, 160),      # deepest level
+    (2, 8, 200, 152, 80),     # ragged query tile + 2-chunk prompt
+    (1, 5, 576, 227, 64),     # SD2.1 head dim, 3-chunk prompt
+    (1, 4, 64, 64, 16),       # tiny test model
+    (1, 1, 64, 64, 64),       # tiny VAE attention (single head)
+    (1, 2, 33, 7, 12),        # unaligned head dim -> plain kernel
+]
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_attention_mfma_vs_plain_vs_torch(engine, case):
+    NB, heads, Sq, Skv, d = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    q = rng.standard_normal((NB, Sq, heads * d)).astype(np.float32)
+    k = rng.standard_normal((NB, Skv, heads * d)).astype(np.float32)
+    v = rng.standard_normal((NB, Skv, heads * d)).astype(np.float32)
+    fast = run_attn(engine, 0, q, k, v, heads)
+    plain = run_attn(engine, 1, q, k, v, heads)
+    def sp(t, S):
+        return torch.from_numpy(t).half().float().view(NB, S, heads, d).transpose(1, 2)
+    att = torch.softmax(sp(q, Sq) @ sp(k, Skv).transpose(-1, -2) * d ** -0.5, dim=-1)
+    ref = (att @ sp(v, Skv)).transpose(1, 2).reshape(NB, Sq, heads * d).numpy()
+    assert rel_l2(plain, ref) < 2e-3
+    assert rel_l2(fast, ref) < 3e-3   # P is rounded to fp16 before the PV product
+    assert rel_l2(fast, plain) < 3e-3
+
+
+def test_attention_softmax_rescale_branch(engine):
+    """Force the online-softmax running max to jump at a later KV tile (one huge score in tile 3)."""
+    NB, heads, S, d = 1, 1, 256, 64
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((NB, S, d)).astype(np.float32)
+    k = rng.standard_normal((NB, S, d)).astype(np.float32)
+    v = rng.standard_normal((NB, S, d)).astype(np.float32)
+    k[0, 200] = q[0, 17] * 4.0   # spike: query 17 vs key 200 (4th tile)
+    fast = run_attn(engine, 0, q, k, v, heads)
+    qt, kt, vt = (torch.from_numpy(t).half().double() for t in (q, k, v))
+    ref = (torch.softmax(qt @ kt.transpose(-1, -2) * d ** -0.5, dim=-1) @ vt).numpy()
+    assert np.abs(fast - ref).max() < 2e-2 and rel_l2(fast, ref) < 3e-3
