@@ -685,7 +685,8 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
                         keep = o->callback(i, t, cb_buf.data(), per, o->callback_user);
                     } else if (o->callback_kind == SDE_CB_DECODED && i != 0 && i % freq == 0) {
                         SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "Decoded callback needs the VAE decoder");
-                        const size_t no = (size_t)B * o->height * o->width * 3;
+                        const int up = e->vae.upscale();
+                        const size_t no = (size_t)B * h * up * w * up * e->vae.out_channels;
                         e->images.ensure(no * 4);
                         decode_dev(e, d_lat, B, h, w, EPI_IMAGE, e->images.as<float>());
                         cb_buf.resize(no);
@@ -708,7 +709,8 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         HIP_CHECK(hipEventRecord(ev1, st));
         if (o->final_latents_out) HIP_CHECK(hipMemcpyAsync(o->final_latents_out, d_lat, per * 4, hipMemcpyDeviceToHost, st));
         if (!o->skip_decode) {                                                                           // :326
-            const size_t no = (size_t)B * o->height * o->width * 3;
+            const int up = e->vae.upscale();  // 8 for Stable Diffusion VAEs => [B,H,W,3]
+            const size_t no = (size_t)B * h * up * w * up * e->vae.out_channels;
             if (o->buffers_on_device) decode_dev(e, d_lat, B, h, w, EPI_IMAGE, images_out);
             else {
                 e->images.ensure(no * 4);

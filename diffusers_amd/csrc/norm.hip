@@ -25,47 +25,46 @@ __device__ __forceinline__ float wave_max(float v)
 __global__ void gn_stats_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, int groups, int TPP, int OPT,
                                 int PR, int ppc, int nchunks, float* part)
 {
-    extern __shared__ float sh[];  // [C] sums | [C] sumsq
+    extern __shared__ float sh[];  // [PR][C] sums | [PR][C] sumsq  (no atomics: results are run-to-run deterministic)
     const int C = C0 + C1;
     const int nb = blockIdx.y, chunk = blockIdx.x;
     const int tid = threadIdx.x;
     const int cx = tid % TPP, pr = tid / TPP;
-    for (int i = tid; i < 2 * C; i += blockDim.x) sh[i] = 0.f;
-    __syncthreads();
     float s[GN_MAX_OPT][8], q[GN_MAX_OPT][8];
 #pragma unroll
     for (int o = 0; o < GN_MAX_OPT; ++o)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[o][j] = 0.f; q[o][j] = 0.f; }
     const int p_begin = chunk * ppc, p_end = min(HW, p_begin + ppc);
-    if (pr < PR) {
-        for (int px = p_begin + pr; px < p_end; px += PR) {
-            const long long row = (long long)nb * HW + px;
-#pragma unroll
-            for (int o = 0; o < GN_MAX_OPT; ++o) {
-                if (o < OPT) {
-                    int c = (cx + o * TPP) * 8;
-                    const half_t* src = c < C0 ? X0 + row * C0 + c : X1 + row * C1 + (c - C0);
-                    half8 v = *(const half8*)src;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[o][j] += f; q[o][j] += f * f; }
-                }
-            }
-        }
+    for (int px = p_begin + pr; px < p_end; px += PR) {
+        const long long row = (long long)nb * HW + px;
 #pragma unroll
         for (int o = 0; o < GN_MAX_OPT; ++o) {
             if (o < OPT) {
                 int c = (cx + o * TPP) * 8;
+                const half_t* src = c < C0 ? X0 + row * C0 + c : X1 + row * C1 + (c - C0);
+                half8 v = *(const half8*)src;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { atomicAdd(&sh[c + j], s[o][j]); atomicAdd(&sh[C + c + j], q[o][j]); }
+                for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[o][j] += f; q[o][j] += f * f; }
             }
+        }
+    }
+    float* shs = sh + (size_t)pr * C;
+    float* shq = sh + (size_t)PR * C + (size_t)pr * C;
+#pragma unroll
+    for (int o = 0; o < GN_MAX_OPT; ++o) {
+        if (o < OPT) {
+            int c = (cx + o * TPP) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { shs[c + j] = s[o][j]; shq[c + j] = q[o][j]; }
         }
     }
     __syncthreads();
     const int cpg = C / groups;
     for (int g = tid; g < groups; g += blockDim.x) {
         float a = 0.f, b = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += sh[c]; b += sh[C + c]; }
+        for (int r = 0; r < PR; ++r)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += sh[(size_t)r * C + c]; b += sh[(size_t)PR * C + (size_t)r * C + c]; }
         float* dst = part + (((long long)nb * nchunks + chunk) * groups + g) * 2;
         dst[0] = a; dst[1] = b;
     }
@@ -154,7 +153,7 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
     const double bytes = (double)a.NB * a.HW * C * 2.0;
     {
         ProfScope ps(ctx, "groupnorm_stats", 0, bytes);
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, a.NB), dim3(TPP * PR), 2 * C * sizeof(float), ctx.stream, a.X0, a.X1, a.C0,
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, a.NB), dim3(TPP * PR), (size_t)2 * PR * C * sizeof(float), ctx.stream, a.X0, a.X1, a.C0,
                            a.C1, a.HW, a.groups, TPP, OPT, PR, ppc, nchunks, part);
     }
     {

@@ -247,13 +247,17 @@ class StableDiffusionTxt2ImgOptions:
                 sn = np.ascontiguousarray(self.step_noise, np.float32)
                 keep.append(sn)
                 o.step_noise = sn.ctypes.data
-            images = None if skip_decode else np.empty((B, self.height, self.width, 3), np.float32)
+            mi = session.info()
+            up = 1 << (mi.vae_n_levels - 1) if mi.vae_loaded else 8   # 8 for SD VAEs => [B,H,W,3]
+            images = None if skip_decode else np.empty((B, h * up, w * up, 3), np.float32)
             images_ptr = images.ctypes.data if images is not None else None
         o.skip_decode = int(skip_decode)
         res = Txt2ImgResult(images=images)
         if self.callback is not None and self.callback_kind != CB_NONE:
             kind = self.callback_kind
             user_cb = self.callback
+            cb_mi = session.info()
+            cb_up = 1 << (cb_mi.vae_n_levels - 1) if cb_mi.vae_loaded else 8
 
             def tramp(step, t, payload, n, _user):
                 arr = None
@@ -262,7 +266,7 @@ class StableDiffusionTxt2ImgOptions:
                     if kind == CB_LATENTS:
                         arr = arr.reshape(B, 4, h, w)
                     elif kind == CB_DECODED:
-                        arr = arr.reshape(B, self.height, self.width, 3)
+                        arr = arr.reshape(B, h * cb_up, w * cb_up, 3)
                     elif kind == CB_APPROXIMATE:
                         arr = arr.reshape(B, h, w, 3)
                 return 1 if user_cb(step, t, arr) else 0

@@ -139,10 +139,8 @@ def test_txt2img_trace_vs_oracle(pipe, oracle_models, kind, steps, guidance, res
         assert rel_l2(res.noise_pred[i], ref["noise_pred"][i]) < 1e-2, (kind, i)
     assert rel_l2(res.final_latents, ref["final"]) < 1e-2
     ref_img = unet_ref.decode_latents(vw, vcfg, torch.from_numpy(ref["final"])).numpy()
-    assert res.images.shape == (B, h * 8 // 4, w * 8 // 4, 3) or res.images.shape == ref_img.shape or True
-    # the tiny VAE has 2 levels (2x upscale): compare on the overlapping definition via a direct decode
-    got_img = pipe.decode_latents(res.final_latents)
-    assert psnr(got_img, ref_img) >= 35.0
+    assert res.images.shape == ref_img.shape          # the tiny VAE has 2 levels => 2x upscale (SD VAEs: 8x)
+    assert psnr(res.images, ref_img) >= 35.0
 
 
 def test_txt2img_size_check_and_callbacks(pipe):
