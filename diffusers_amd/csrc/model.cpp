@@ -457,7 +457,11 @@ void VaeDecoderModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilde
     mid_att.q = b.linear({a + ".query.weight"}, {a + ".query.bias"});
     mid_att.k = b.linear({a + ".key.weight"}, {a + ".key.bias"});
     mid_att.v = b.linear({a + ".value.weight"}, {a + ".value.bias"});
-    mid_att.qkv = b.linear({a + ".query.weight", a + ".key.weight", a + ".value.weight"}, {a + ".query.bias", a + ".key.bias", a + ".value.bias"});
+    {   // merged copy for the flash path (narrow VAEs); not counted twice
+        const int64_t before = b.params;
+        mid_att.qkv = b.linear({a + ".query.weight", a + ".key.weight", a + ".value.weight"}, {a + ".query.bias", a + ".key.bias", a + ".value.bias"});
+        b.params = before;
+    }
     mid_att.proj = b.linear({a + ".proj_attn.weight"}, {a + ".proj_attn.bias"});
     mid_att.C = mid_att.q.N;
     mid_res1 = build_resnet(b, "decoder.mid_block.resnets.1", false);

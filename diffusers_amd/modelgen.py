@@ -389,26 +389,37 @@ class GraphWriter:
         return self.binary("Mul", scope, x, s)
 
     def serialize(self, path: str, inputs: Sequence[str], outputs: Sequence[str], external_file: str | None):
+        """Streams the ModelProto to disk piece by piece (no quadratic byte-string concatenation)."""
         base = os.path.dirname(os.path.abspath(path))
-        g = b"".join(_ld(1, n) for n in self.nodes) + _ld(2, b"torch_jit")
+        pieces: List = [_ld(1, n) for n in self.nodes]
+        pieces.append(_ld(2, b"torch_jit"))
         if external_file:
             off = 0
             with open(os.path.join(base, external_file), "wb") as f:
                 for name, arr in self.inits:
                     arr = np.ascontiguousarray(arr)
-                    g += _ld(5, _tensor(name, arr, (external_file, off)))
-                    f.write(arr.tobytes())
+                    pieces.append(_ld(5, _tensor(name, arr, (external_file, off))))
+                    f.write(memoryview(arr).cast("B"))
                     off += arr.nbytes
         else:
             for name, arr in self.inits:
-                g += _ld(5, _tensor(name, arr))
+                arr = np.ascontiguousarray(arr)
+                head = b"".join(_iv(1, int(d)) for d in arr.shape) + _iv(2, _NP2ONNX[arr.dtype]) + _ld(8, name.encode())
+                raw_hdr = _vi((9 << 3) | 2) + _vi(arr.nbytes)
+                tlen = len(head) + len(raw_hdr) + arr.nbytes
+                pieces.append(_vi((5 << 3) | 2) + _vi(tlen) + head + raw_hdr)
+                pieces.append(memoryview(arr).cast("B") if arr.nbytes else b"")
         for n in inputs:
-            g += _ld(11, _ld(1, n.encode()))
+            pieces.append(_ld(11, _ld(1, n.encode())))
         for n in outputs:
-            g += _ld(12, _ld(1, n.encode()))
-        model = _iv(1, 8) + _ld(2, b"pytorch") + _ld(3, b"1.13.1") + _ld(7, g) + _ld(8, _ld(1, b"") + _iv(2, 15))
+            pieces.append(_ld(12, _ld(1, n.encode())))
+        glen = sum(len(p) for p in pieces)
         with open(path, "wb") as f:
-            f.write(model)
+            f.write(_iv(1, 8) + _ld(2, b"pytorch") + _ld(3, b"1.13.1"))
+            f.write(_vi((7 << 3) | 2) + _vi(glen))
+            for p in pieces:
+                f.write(p)
+            f.write(_ld(8, _ld(1, b"") + _iv(2, 15)))
 
 
 # --------------------------------------------------------------------------- graph emitters

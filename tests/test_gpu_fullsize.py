@@ -1,0 +1,96 @@
+"""GPU: parity at BASELINE.json's full sizes — SD v1.5 geometry (860 M-parameter UNet, 64x64 latents, 512x512 images),
+random-init weights written in the sd2pyke ONNX dialect and loaded by the product loader, against the CPU oracle.
+Bars (north_star): per-step noise prediction rel-L2 <= 1e-2 (fp16), final image PSNR >= 35 dB."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+MODEL_DIR = os.environ.get("SDE_BENCH_MODEL_DIR", "/tmp/sde_bench_sd15_f16")
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 10 * np.log10(1.0 / max(mse, 1e-20))
+
+
+@pytest.fixture(scope="module")
+def sd15():
+    from diffusers_amd import modelgen
+    from diffusers_amd.pipeline import StableDiffusionPipeline
+    from oracle import model_dir
+    if not os.path.exists(os.path.join(MODEL_DIR, ".complete")):
+        modelgen.write_model_dir(MODEL_DIR, modelgen.unet_config(), modelgen.vae_config(), seed=42, dtype=np.float16)
+        open(os.path.join(MODEL_DIR, ".complete"), "w").write("ok")
+    pipe = StableDiffusionPipeline(MODEL_DIR)
+    uw, ucfg = model_dir.load_unet(MODEL_DIR)
+    vw, vcfg = model_dir.load_vae_decoder(MODEL_DIR)
+    t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    yield pipe, t(uw), ucfg, t(vw), vcfg
+    pipe.close()
+
+
+def test_sd15_architecture_inferred(sd15):
+    pipe = sd15[0]
+    mi = pipe.info()
+    assert list(mi.block_out_channels[:4]) == [320, 640, 1280, 1280] and mi.layers_per_block == 2
+    assert list(mi.num_heads[:4]) == [8, 8, 8, 8] and mi.cross_attention_dim == 768
+    assert list(mi.down_attn[:4]) == [1, 1, 1, 0]
+    assert 855e6 < mi.unet_params < 865e6 and 49e6 < mi.vae_params < 50e6
+    assert list(mi.vae_block_out_channels[:4]) == [512, 512, 256, 128]
+
+
+@pytest.mark.parametrize("S,t", [(77, 946.42), (227, 17.0)])
+def test_sd15_unet_forward(sd15, S, t):
+    from oracle import unet_ref
+    pipe, uw, ucfg, _, _ = sd15
+    rng = np.random.default_rng(S)
+    x = rng.standard_normal((2, 4, 64, 64)).astype(np.float32)
+    ehs = (rng.standard_normal((2, S, 768)) * 0.5).astype(np.float32)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), t, torch.from_numpy(ehs)).numpy()
+    got = pipe.unet(x, t, ehs)
+    assert np.isfinite(got).all()
+    assert rel_l2(got, ref) < 1e-2, rel_l2(got, ref)
+
+
+def test_sd15_txt2img_three_steps_and_decode(sd15):
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionTxt2ImgOptions
+    from oracle import schedulers as S, txt2img as T, unet_ref
+    pipe, uw, ucfg, vw, vcfg = sd15
+    rng = np.random.default_rng(21)
+    ehs = (rng.standard_normal((2, 77, 768)) * 0.5).astype(np.float32)
+    init = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
+    unet = lambda x, t, e: unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), t, torch.from_numpy(e)).numpy()
+    with torch.no_grad():
+        ref = T.run(unet, S.make("dpmpp"), ehs, init, 3, 7.5)
+        ref_img = unet_ref.decode_latents(vw, vcfg, torch.from_numpy(ref["final"])).numpy()
+    opts = StableDiffusionTxt2ImgOptions(height=512, width=512, steps=3, text_embeddings=ehs, batch_size=1, init_latents=init)
+    res = opts.run(pipe, N.DPMSolverMultistepScheduler.stable_diffusion_v1_optimized_default(), trace=True)
+    for i in range(3):
+        assert rel_l2(res.noise_pred[i], ref["noise_pred"][i]) < 1e-2, i
+    assert res.images.shape == (1, 512, 512, 3)
+    assert psnr(res.images, ref_img) >= 35.0, psnr(res.images, ref_img)
+
+
+def test_sd15_batch_invariance_and_determinism(sd15):
+    """Size-independent properties at full width: a sample's prediction does not depend on its batch neighbours
+    (independent prompts shard over GPUs), and repeated calls are bitwise identical."""
+    pipe = sd15[0]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((4, 4, 64, 64)).astype(np.float32)
+    ehs = (rng.standard_normal((4, 77, 768)) * 0.5).astype(np.float32)
+    full = pipe.unet(x, 500.0, ehs)
+    again = pipe.unet(x, 500.0, ehs)
+    assert np.array_equal(full, again)
+    part = pipe.unet(x[1:3], 500.0, ehs[1:3])
+    assert rel_l2(part, full[1:3]) < 2e-3   # tile shapes change with the batch, so fp32 summation order may differ
