@@ -14,6 +14,8 @@
 // Roofline: MFMA-bound; algorithmic flops 4*Sq*Skv*d per (batch, head).
 //
 // Plain path: one thread per (batch, head, query) — test sizes, odd head dims, cross-check.
+#include <type_traits>
+
 #include "kernels.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -28,8 +30,16 @@ struct AttnDev {
     float scale_log2e;
 };
 
-template <int DQK, int DVT>
-__global__ __launch_bounds__(256) void attn_mfma_kernel(AttnDev p)
+// One K/V tile of work for a wave: scores, online softmax, PV.  MASK = the tile holds keys >= Skv.
+// Softmax runs in the log2 domain on raw scores: p = exp2(s*c - m*c), c = scale*log2(e) (one FMA per element).
+// The running max is only raised when it grows by more than RESCALE_THR (in log2 units): P then stays <= 2^THR,
+// which fp16 P and fp32 accumulators tolerate, and the O rescale pass is skipped for almost every tile.
+#define ATTN_RESCALE_THR 8.0f
+
+// ONES: the head dim leaves a spare column in the last 16-wide V tile (d < 16*DVT); it is filled with 1.0 so the PV product
+// also accumulates the softmax denominator (row DVT*16-1 of O^T) and the VALU row sum disappears.
+template <int DQK, int DVT, bool ONES>
+__global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(AttnDev p)
 {
     constexpr int KROW = DQK + 8;        // padded K-tile row (elements)
     constexpr int VROW = DVT * 16 + 8;   // padded V-tile row (elements); row stride stays a multiple of 16 B
@@ -42,6 +52,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnDev p)
     const int nb = blockIdx.z, head = blockIdx.y;
     const int q0 = blockIdx.x * 128 + wid * 32;
     const int d = p.d;
+    const float csl = p.scale_log2e;
 
     const half_t* Qb = p.Q + (long long)nb * p.Sq * p.ldq + head * d;
     const half_t* Kb = p.K + (long long)nb * p.Skv * p.ldk + head * d;
@@ -63,25 +74,62 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnDev p)
     floatx4 o[DVT][2];
 #pragma unroll
     for (int a = 0; a < DVT; ++a) { o[a][0] = floatx4{0, 0, 0, 0}; o[a][1] = floatx4{0, 0, 0, 0}; }
-    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};
+    float mrow[2] = {-INFINITY, -INFINITY}, lrow[2] = {0.f, 0.f};   // mrow in raw-score units
 
-    for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
-        __syncthreads();  // everyone done with the previous tile
-        // stage K: 64 rows x DQK/8 chunks ; V: 64 rows x DVT*2 chunks (zero beyond Skv / d)
-        for (int idx = tid; idx < 64 * (DQK / 8); idx += 256) {
-            int r = idx / (DQK / 8), c = (idx - r * (DQK / 8)) * 8;
+    // register-staged K/V tiles: the loads of tile t+1 are issued before tile t is computed.
+    // Per-thread slots are fixed across tiles; rows past Skv are clamped to the last key (masked later), pad columns read zeros.
+    constexpr int KCH = DQK / 8, VCH = DVT * 2;
+    constexpr int KN = (64 * KCH + 255) / 256, VN = (64 * VCH + 255) / 256;
+    half8 kreg[KN], vreg[VN];
+    int krow[KN], vrow[VN], kcol[KN], vcol[VN];
+    int klds[KN], vlds[VN];
+#pragma unroll
+    for (int i = 0; i < KN; ++i) {
+        int idx = tid + i * 256;
+        int r = idx / KCH, c = (idx - r * KCH) * 8;
+        krow[i] = r; kcol[i] = (idx < 64 * KCH && c < d) ? c : -1; klds[i] = idx < 64 * KCH ? r * KROW + c : -1;
+    }
+#pragma unroll
+    for (int i = 0; i < VN; ++i) {
+        int idx = tid + i * 256;
+        int r = idx / VCH, c = (idx - r * VCH) * 8;
+        vrow[i] = r; vcol[i] = (idx < 64 * VCH && c < d) ? c : -1; vlds[i] = idx < 64 * VCH ? r * VROW + c : -1;
+    }
+    const int last_key = p.Skv - 1;
+    auto load_tile = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < KN; ++i) {
             half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kv0 + r < p.Skv && c < d) v = *(const half8*)(Kb + (long long)(kv0 + r) * p.ldk + c);
-            *(half8*)(sK + r * KROW + c) = v;
+            if (kcol[i] >= 0) v = *(const half8*)(Kb + (long long)min(kv0 + krow[i], last_key) * p.ldk + kcol[i]);
+            kreg[i] = v;
         }
-        for (int idx = tid; idx < 64 * (DVT * 2); idx += 256) {
-            int r = idx / (DVT * 2), c = (idx - r * (DVT * 2)) * 8;
+#pragma unroll
+        for (int i = 0; i < VN; ++i) {
             half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kv0 + r < p.Skv && c < d) v = *(const half8*)(Vb + (long long)(kv0 + r) * p.ldv + c);
-            *(half8*)(sV + r * VROW + c) = v;
+            if (vcol[i] >= 0) v = *(const half8*)(Vb + (long long)min(kv0 + vrow[i], last_key) * p.ldv + vcol[i]);
+            vreg[i] = v;
         }
-        __syncthreads();
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < KN; ++i) if (kcol[i] >= 0) *(half8*)(sK + klds[i]) = kreg[i];
+#pragma unroll
+        for (int i = 0; i < VN; ++i) if (vcol[i] >= 0) *(half8*)(sV + vlds[i]) = vreg[i];
+    };
+    // pad columns (>= d) never change: written once.  ONES: the very last V column holds 1.0 (softmax denominator).
+#pragma unroll
+    for (int i = 0; i < KN; ++i)
+        if (kcol[i] < 0 && klds[i] >= 0) *(half8*)(sK + klds[i]) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < VN; ++i)
+        if (vcol[i] < 0 && vlds[i] >= 0) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ONES && vlds[i] - vrow[i] * VROW == DVT * 16 - 8) z[7] = (half_t)1.0f;
+            *(half8*)(sV + vlds[i]) = z;
+        }
 
+    auto tile = [&](int kv0, auto mask_tag) {
+        constexpr bool MASK = decltype(mask_tag)::value;
         // scores S^T[key][q]: s[kt][qt][r] <-> key = kv0 + 16*kt + 4*fg + r, q = q0 + 16*qt + fr
         floatx4 s[4][2];
 #pragma unroll
@@ -95,73 +143,105 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(AttnDev p)
                 s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
             }
         }
-        // online softmax per query column
-        half8 pf[2][2];  // [qt][k-step of 32 keys] B operand of the PV product
+        // phase 1 (per q-tile): mask, running max, deferred rescale (branchy, short)
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-            float mx = -INFINITY;
+            if (MASK) {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (kv0 + kt * 16 + fg * 4 + r >= p.Skv) s[kt][qt][r] = -INFINITY;
+            }
+            float mx = s[0][qt][0];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = s[kt][qt][r] * p.scale_log2e;
-                    if (kv0 + kt * 16 + fg * 4 + r >= p.Skv) v = -INFINITY;
-                    s[kt][qt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            float mnew = fmaxf(mrow[qt], mx);
-            float alpha = exp2f(mrow[qt] - mnew);
-            mrow[qt] = mnew;
+            // deferred rescale: raise the running max only when it grows by more than THR (log2 units)
+            const bool grow = mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY;
+            if (__any(grow)) {
+                float mnew = grow ? mx : mrow[qt];
+                float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * csl);   // exp2(-inf) = 0 on the first tile
+                if (mrow[qt] == mnew) alpha = 1.0f;
+                mrow[qt] = mnew;
+                lrow[qt] *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+            }
+        }
+        // phase 2 (straight line): V^T fragments, then exp / PV per q-tile so that the second tile's exponentials can
+        // be scheduled between the first tile's PV MFMAs.
+        // A operand via transposed LDS reads: lane 4q'+p' of a 16-lane group addresses row (key) q', columns 4p'..4p'+3
+        // and receives column (lane&15).  k-slot (fg, j): j<4 -> key tile 2*s2, reg j ; j>=4 -> key tile 2*s2+1, reg j-4.
+        const int tq = fr >> 2, tp = fr & 3;
+        auto read_v = [&](int s2, int dt) {
+            const half_t* a0 = sV + (s2 * 32 + fg * 4 + tq) * VROW + dt * 16 + tp * 4;
+            fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
+            fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(a0 + 16 * VROW));
+            half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
+            half8 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { v[r] = l4[r]; v[4 + r] = h4[r]; }
+            return v;
+        };
+        constexpr bool HOLD_V = DVT <= 4;   // keep the V^T fragments in registers for both q-tiles when they fit
+        half8 vf[HOLD_V ? 2 : 1][HOLD_V ? DVT : 1];
+        if (HOLD_V) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt) vf[HOLD_V ? s2 : 0][HOLD_V ? dt : 0] = read_v(s2, dt);
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float mc = mrow[qt] * csl;
             float sum = 0.f;
+            half8 pf[2];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float e = exp2f(s[kt][qt][r] - mnew);
-                    s[kt][qt][r] = e;
-                    sum += e;
+                    float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], csl, -mc));
+                    if (!ONES) sum += e;
+                    pf[kt >> 1][(kt & 1) * 4 + r] = (half_t)e;
                 }
-            lrow[qt] = lrow[qt] * alpha + sum;
+            if (!ONES) lrow[qt] += sum;
 #pragma unroll
-            for (int dt = 0; dt < DVT; ++dt)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
-            // k-slot (fg, j): j<4 -> key tile 2*s2, reg j ; j>=4 -> key tile 2*s2+1, reg j-4
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                half8 v;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { v[r] = (half_t)s[2 * s2][qt][r]; v[4 + r] = (half_t)s[2 * s2 + 1][qt][r]; }
-                pf[qt][s2] = v;
-            }
+                for (int dt = 0; dt < DVT; ++dt) {
+                    half8 v = HOLD_V ? vf[HOLD_V ? s2 : 0][HOLD_V ? dt : 0] : read_v(s2, dt);
+                    o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, pf[s2], o[dt][qt], 0, 0, 0);
+                }
         }
-        // O^T[d][q] += V^T[d][key] P^T[key][q]; A operand via transposed LDS reads:
-        // lane 4q'+p' of a 16-lane group addresses row (key) q', columns 4p'..4p'+3 and receives column (lane&15).
-        const int tq = fr >> 2, tp = fr & 3;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-#pragma unroll
-            for (int dt = 0; dt < DVT; ++dt) {
-                const half_t* a0 = sV + (s2 * 32 + fg * 4 + tq) * VROW + dt * 16 + tp * 4;
-                fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
-                fp16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)(a0 + 16 * VROW));
-                half8 vf;
-                half4 l4 = __builtin_bit_cast(half4, lo), h4 = __builtin_bit_cast(half4, hi);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { vf[r] = l4[r]; vf[4 + r] = h4[r]; }
-                o[dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[0][s2], o[dt][0], 0, 0, 0);
-                o[dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf[1][s2], o[dt][1], 0, 0, 0);
-            }
-        }
+    };
+
+    constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
+    if (PREFETCH) load_tile(0);
+    for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
+        if (!PREFETCH) load_tile(kv0);
+        __syncthreads();  // everyone done reading the previous tile
+        store_tile();
+        __syncthreads();
+        if (PREFETCH && kv0 + 64 < p.Skv) load_tile(kv0 + 64);
+        if (kv0 + 64 > p.Skv) tile(kv0, std::true_type{});   // block-uniform branch
+        else tile(kv0, std::false_type{});
     }
     // finish: o[dt][qt][r] <-> d index 16*dt + 4*fg + r, q = q0 + 16*qt + fr
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = lrow[qt];
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
+        float l;
+        if (ONES) l = __shfl(o[DVT - 1][qt][3], 48 + fr);   // row 16*DVT-1 of O^T lives in lane group 3, register 3
+        else {
+            l = lrow[qt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
         float inv = 1.0f / l;
         int q = q0 + qt * 16 + fr;
         if (q >= p.Sq) continue;
@@ -229,7 +309,8 @@ template <int DQK, int DVT>
 static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
 {
     dim3 grid(cdiv(p.Sq, 128), p.heads, p.NB);
-    hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT>), grid, dim3(256), 0, ctx.stream, p);
+    if (p.d < DVT * 16) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true>), grid, dim3(256), 0, ctx.stream, p);
+    else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false>), grid, dim3(256), 0, ctx.stream, p);
 }
 
 void launch_attention(const LaunchCtx& ctx, const AttnArgs& a)

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Per-shape kernel timings (HIP events inside the engine) for the SD1.5 UNet's contraction shapes at UNet batch 16."""
+import sys, os, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from diffusers_amd import _lib, modelgen
+from diffusers_amd.pipeline import StableDiffusionPipeline
+
+NB = int(os.environ.get("NB", "16"))
+CONVS = [  # H, Cin, Cout, k, stride, ups
+    (64, 320, 320, 3, 1, 0), (64, 640, 320, 3, 1, 0), (32, 640, 640, 3, 1, 0), (32, 1280, 640, 3, 1, 0), (16, 1280, 1280, 3, 1, 0),
+    (16, 2560, 1280, 3, 1, 0), (8, 1280, 1280, 3, 1, 0), (8, 2560, 1280, 3, 1, 0), (32, 320, 320, 3, 1, 1), (64, 320, 320, 3, 2, 0),
+    (64, 320, 320, 1, 1, 0), (64, 320, 960, 1, 1, 0), (64, 1280, 320, 1, 1, 0), (32, 640, 640, 1, 1, 0), (32, 2560, 640, 1, 1, 0),
+    (16, 1280, 1280, 1, 1, 0), (16, 5120, 1280, 1, 1, 0), (64, 320, 2560, 1, 1, 0),
+]
+ATTN = [(8, 4096, 4096, 40), (8, 1024, 1024, 80), (8, 256, 256, 160), (8, 4096, 77, 40), (8, 1024, 77, 80)]
+
+
+def main():
+    d = "/tmp/mb_tiny"
+    if not os.path.exists(d + "/unet.onnx"):
+        modelgen.write_model_dir(d, modelgen.unet_config(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False),
+                                                         cross_attention_dim=64, num_heads=4),
+                                 modelgen.vae_config(block_out_channels=(64, 128), layers_per_block=1), seed=1)
+    p = StableDiffusionPipeline(d)
+    L = _lib.lib()
+    rng = np.random.default_rng(0)
+    reps = 4
+    for (H, Cin, Cout, k, stride, ups) in CONVS:
+        x = rng.standard_normal((NB, H, H, Cin), dtype=np.float32)
+        w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
+        Hv = 2 * H if ups else H
+        Ho = (Hv - 1) // stride + 1 if k == 3 else Hv
+        out = np.empty((NB, Ho, Ho, Cout), np.float32)
+        _lib.check(L.sde_test_conv(p._h, 0, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
+        p.profile_reset(); p.profile(True)
+        for _ in range(reps):
+            _lib.check(L.sde_test_conv(p._h, 0, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
+        st = [s for s in p.profile_get() if "mfma" in s["name"]]
+        p.profile(False)
+        for s in st:
+            us = s["total_ms"] / s["launches"] * 1e3
+            print(f"conv k{k} s{stride} u{ups} {H:3d}^2 {Cin:5d}->{Cout:5d}  M={NB*Ho*Ho:6d}  {us:9.1f} us  {s['flops']/s['launches']/us/1e6:7.1f} TFLOP/s", flush=True)
+    for (heads, Sq, Skv, dd) in ATTN:
+        q = rng.standard_normal((NB, Sq, heads * dd), dtype=np.float32)
+        kk = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
+        v = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
+        out = np.empty_like(q)
+        _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data))
+        p.profile_reset(); p.profile(True)
+        for _ in range(reps):
+            _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data))
+        st = [s for s in p.profile_get() if "attn" in s["name"]]
+        p.profile(False)
+        for s in st:
+            us = s["total_ms"] / s["launches"] * 1e3
+            print(f"attn h{heads} Sq={Sq} Skv={Skv} d={dd}  {us:9.1f} us  {s['flops']/s['launches']/us/1e6:7.1f} TFLOP/s", flush=True)
+    p.close()
+
+
+if __name__ == "__main__":
+    main()
