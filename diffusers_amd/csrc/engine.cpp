@@ -119,7 +119,7 @@ struct sde_engine {
     VaeDecoderModel vae;
     bool has_unet = false, has_vae = false;
     Arena arena;
-    DevBuf arena_buf, zeros, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps;
+    DevBuf arena_buf, zeros, splitk_ws, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps;
     std::vector<half_t*> kv_ptrs;
     std::mutex mu;  // one forward at a time per engine (reference: Session is Send+Sync; here calls serialize)
     // cached arena sizing
@@ -249,6 +249,9 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
         e->prof.stream = e->stream;
         e->zeros.ensure(4096, true, e->stream);
         e->ctx.stream = e->stream; e->ctx.prof = &e->prof; e->ctx.zeros = e->zeros.as<half_t>(); e->ctx.force_naive = o.force_naive != 0;
+        e->splitk_ws.ensure((size_t)64 << 20);
+        e->ctx.splitk_ws = e->splitk_ws.as<float>(); e->ctx.splitk_ws_bytes = e->splitk_ws.cap;
+        if (const char* sk = getenv("SDE_SPLITK")) e->ctx.splitk_force = atoi(sk);   // tuning hook (0 = heuristic, 1 = off)
         e->wb.ctx = e->ctx; e->wb.ctx.prof = nullptr;
         if (o.load_unet && !unet_path.empty()) {
             OnnxModel m; WeightMap w;

@@ -17,6 +17,8 @@
 // (K-chunk not a multiple of 64, tiny test models) and as an on-device cross-check.
 #include "kernels.h"
 
+#include <algorithm>
+
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
@@ -34,6 +36,7 @@ struct GemmDev {
     long long sA, sW, sD, sR;
     const half_t* zeros;
     int nbm, nbn;
+    int splitk; float* ws;   // splitk > 1: raw fp32 partial tiles go to ws[ks][M][Npad], reduced by splitk_reduce_kernel
 };
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -155,12 +158,15 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
     for (int i = 0; i < BP; ++i) w_ptr[i] = Wp + (long long)(n0 + i * 32 + srow) * p.K + lchunk * 8;
 
     const int Ctot = p.C0 + p.C1;
-    const int nk = p.K >> 6;
+    const int nk_all = p.K >> 6;
+    const int ks = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * ks / p.splitk);
+    const int nk = (int)((long long)nk_all * (ks + 1) / p.splitk) - kt0;
 
     auto stage = [&](int kt, int buf) {
         char* sa = smem + buf * STAGE;
         char* sb = sa + A_BYTES;
-        const int k0 = kt << 6;
+        const int k0 = (kt0 + kt) << 6;
         int tap = 0, c0 = k0;
         if (CONV) { tap = k0 / Ctot; c0 = k0 - tap * Ctot; }
         const half_t* src = A0; int ld = p.lda0; int cc = c0;
@@ -228,6 +234,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
 
     // epilogue: acc[nt][mt][r] <-> n = n0 + wn*BN/2 + nt*16 + 4*fg + r ; m = m0 + wm*BM/2 + mt*16 + fr
     const long long zD = z * p.sD, zR = z * p.sR;
+    if (p.splitk > 1) {
+        float* ws = p.ws + (long long)ks * p.M * p.Npad;
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+            const int m = m0 + wm * (BM / 2) + mt * 16 + fr;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                int n = n0 + wn * (BN / 2) + nt * 16 + 4 * fg;
+                *(floatx4*)(ws + (long long)m * p.Npad + n) = acc[nt][mt];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
         const int m = m0 + wm * (BM / 2) + mt * 16 + fr;
@@ -246,6 +266,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------ split-K reduction + epilogue
+__global__ void splitk_reduce_kernel(GemmDev p)
+{
+    const int groups = p.Npad >> 2;
+    long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)p.M * groups) return;
+    const int m = (int)(gid / groups), n = (int)(gid - (long long)m * groups) * 4;
+    const float* ws = p.ws + (long long)m * p.Npad + n;
+    const long long slab = (long long)p.M * p.Npad;
+    floatx4 v = *(const floatx4*)ws;
+    for (int k = 1; k < p.splitk; ++k) v += *(const floatx4*)(ws + k * slab);
+    epilogue4(p, m, n, v, v, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------ plain kernel
@@ -316,7 +350,7 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     p.Hs = a.ups ? a.Hi / 2 : a.Hi; p.Ws = a.ups ? a.Wi / 2 : a.Wi;
     p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
     p.epi = a.epi; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
-    p.nbm = p.nbn = 0;
+    p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr;
     return p;
 }
 
@@ -347,8 +381,21 @@ static void launch_mfma(const LaunchCtx& ctx, GemmDev& p, int batch)
     }
     p.nbm = cdiv(p.M, BM);
     p.nbn = p.Npad / BN;
-    dim3 grid(p.nbm * p.nbn, 1, batch);
+    // split-K when the tile grid cannot fill the chip (2 blocks/CU x 256 CUs) and K is long: partial slabs + reduce kernel
+    p.splitk = 1;
+    const int tiles = p.nbm * p.nbn, nk = p.K >> 6;
+    if (batch == 1 && p.epi != EPI_GEGLU && ctx.splitk_ws && tiles < 512 && nk >= 32) {
+        int sk = std::min(std::min((512 + tiles / 2) / tiles, nk / 16), 8);   // one full wave of blocks (2 per CU)
+        if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
+        while (sk > 1 && (size_t)sk * p.M * p.Npad * sizeof(float) > ctx.splitk_ws_bytes) --sk;
+        if (sk > 1) { p.splitk = sk; p.ws = ctx.splitk_ws; }
+    }
+    dim3 grid(p.nbm * p.nbn, p.splitk, batch);
     hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx.stream, p);
+    if (p.splitk > 1) {
+        long long total = (long long)p.M * (p.Npad >> 2);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);
+    }
 }
 
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
@@ -364,7 +411,14 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (a.R ? 2 : 1)) * 2.0 * a.batch;
     if (!ctx.force_naive && gemm_mfma_supported(a)) {
         ProfScope ps(ctx, a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU ? "gemm_geglu_mfma" : "gemm_mfma"), flops, bytes);
-        const bool small_m = a.M <= 2048;
+        // tile height: 128 rows unless that leaves the chip (256 CUs x 2 blocks) under-filled and split-K (<= 4 ways,
+        // long K only) cannot make up for it -> 64 rows.  Measured on MI355X at UNet batch 16 (tools/microbench.py).
+        static const int bm64_env = getenv("SDE_BM64") ? atoi(getenv("SDE_BM64")) : -1;   // tuning hook
+        const int nbn_ = a.Npad / ((a.Npad % 160 == 0 && a.epi != EPI_GEGLU) ? 160 : 128);
+        const int tiles128 = cdiv(a.M, 128) * nbn_ * a.batch;
+        const bool can_split = a.batch == 1 && a.epi != EPI_GEGLU && ctx.splitk_ws && (a.K >> 6) >= 64;
+        bool small_m = tiles128 < 512 && !(can_split && tiles128 >= 128);
+        if (bm64_env >= 0) small_m = a.M <= bm64_env;
         const bool bn160 = (a.Npad % 160 == 0) && a.epi != EPI_GEGLU;
         if (a.taps == 9) {
             if (bn160) { if (small_m) launch_mfma<64, 160, true>(ctx, p, a.batch); else launch_mfma<128, 160, true>(ctx, p, a.batch); }

@@ -14,6 +14,9 @@ struct LaunchCtx {
     Profiler* prof = nullptr;
     const half_t* zeros = nullptr;  // >= 256 B of device zeros (source for padded taps / tail rows)
     bool force_naive = false;
+    float* splitk_ws = nullptr;     // fp32 partial-tile workspace for split-K GEMMs (null: split-K off)
+    size_t splitk_ws_bytes = 0;
+    int splitk_force = 0;           // tuning hook: >0 forces this split factor where split-K applies
 };
 // RAII bracket: records HIP events around a launch when profiling is on.
 struct ProfScope {

@@ -46,6 +46,9 @@ CONV_CASES = [
     (3, 8, 8, 192, 320, 1, 1, 0),       # 1x1 / linear
     (1, 64, 64, 64, 4, 3, 1, 0),        # conv_out-like: N=4 padded to one tile
     (1, 7, 5, 24, 40, 3, 1, 0),         # unaligned channels -> plain kernel on both paths
+    (2, 8, 8, 1280, 1280, 3, 1, 0),     # few tiles, long K -> split-K partial slabs + reduce kernel
+    (1, 16, 16, 640, 320, 3, 2, 0),     # split-K with stride 2
+    (1, 24, 24, 2048, 192, 1, 1, 0),    # split-K on a linear layer, ragged M tile and padded N
 ]
 
 

@@ -26,7 +26,9 @@ def main():
     L = _lib.lib()
     rng = np.random.default_rng(0)
     reps = 4
-    for (H, Cin, Cout, k, stride, ups) in CONVS:
+    only = os.environ.get("MB_ONLY", "")
+    convs = [c for c in CONVS if not only or (only == "small" and NB * c[0] * c[0] <= 4096) or (only == "big" and NB * c[0] * c[0] > 4096)]
+    for (H, Cin, Cout, k, stride, ups) in convs:
         x = rng.standard_normal((NB, H, H, Cin), dtype=np.float32)
         w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
         Hv = 2 * H if ups else H
@@ -41,7 +43,7 @@ def main():
         for s in st:
             us = s["total_ms"] / s["launches"] * 1e3
             print(f"conv k{k} s{stride} u{ups} {H:3d}^2 {Cin:5d}->{Cout:5d}  M={NB*Ho*Ho:6d}  {us:9.1f} us  {s['flops']/s['launches']/us/1e6:7.1f} TFLOP/s", flush=True)
-    for (heads, Sq, Skv, dd) in ATTN:
+    for (heads, Sq, Skv, dd) in ([] if only else ATTN):
         q = rng.standard_normal((NB, Sq, heads * dd), dtype=np.float32)
         kk = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
         v = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
