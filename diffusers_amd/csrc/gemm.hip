@@ -19,91 +19,7 @@
 
 #include <algorithm>
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-
-#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
-#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-
-struct GemmDev {
-    const half_t* A0; const half_t* A1;
-    int C0, C1, lda0, lda1;
-    int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws;
-    const half_t* W; int Npad;
-    const float* bias; const half_t* R; int ldr;
-    half_t* D; float* Df; int ldd; int epi; float alpha;
-    long long sA, sW, sD, sR;
-    const half_t* zeros;
-    int nbm, nbn;
-    int splitk; float* ws;   // splitk > 1: raw fp32 partial tiles go to ws[ks][M][Npad], reduced by splitk_reduce_kernel
-};
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-
-// ------------------------------------------------------------------------------------------ epilogue (shared)
-// Handles 4 consecutive columns n..n+3 of row m held in v[0..3].
-__device__ __forceinline__ void epilogue4(const GemmDev& p, int m, int n, floatx4 v, floatx4 vg, long long zD, long long zR)
-{
-    if (m >= p.M) return;
-    if (p.epi == EPI_STD) {
-        if (n >= p.N) return;
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = v[r] * p.alpha;
-        if (p.bias) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] += p.bias[n + r];
-        }
-        if (n + 3 < p.N) {
-            if (p.R) {
-                half4 rr = *(const half4*)(p.R + zR + (long long)m * p.ldr + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] += (float)rr[r];
-            }
-            half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-            *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
-        } else {
-            for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                float x = o[r];
-                if (p.R) x += (float)p.R[zR + (long long)m * p.ldr + n + r];
-                p.D[zD + (long long)m * p.ldd + n + r] = (half_t)x;
-            }
-        }
-    } else if (p.epi == EPI_GEGLU) {
-        // v = value columns, vg = gate columns for output columns j..j+3 (j passed in n)
-        int half_n = p.N >> 1;
-        if (n >= half_n) return;
-        half4 h;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float a = v[r], g = vg[r];
-            if (p.bias && n + r < half_n) { a += p.bias[n + r]; g += p.bias[half_n + n + r]; }
-            h[r] = (half_t)(a * gelu_erf(g));
-        }
-        if (n + 3 < half_n) *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
-        else for (int r = 0; r < 4 && n + r < half_n; ++r) p.D[zD + (long long)m * p.ldd + n + r] = h[r];
-    } else if (p.epi == EPI_NCHW_F32) {
-        int hw = p.Ho * p.Wo;
-        int nb = m / hw, pix = m - nb * hw;
-        for (int r = 0; r < 4 && n + r < p.N; ++r) {
-            float x = v[r] + (p.bias ? p.bias[n + r] : 0.f);
-            p.Df[zD + ((long long)nb * p.N + n + r) * hw + pix] = x;
-        }
-    } else if (p.epi == EPI_IMAGE) {
-        for (int r = 0; r < 4 && n + r < p.N; ++r) {
-            float x = v[r] + (p.bias ? p.bias[n + r] : 0.f);
-            x = x / 2.0f + 0.5f;
-            x = fminf(fmaxf(x, 0.0f), 1.0f);
-            p.Df[zD + (long long)m * p.N + n + r] = x;
-        }
-    } else {  // EPI_TRANS
-        for (int r = 0; r < 4 && n + r < p.N; ++r) {
-            float x = v[r] * p.alpha + (p.bias ? p.bias[n + r] : 0.f);
-            p.D[zD + (long long)(n + r) * p.ldd + m] = (half_t)x;
-        }
-    }
-}
+#include "gemm_common.h"
 
 // ------------------------------------------------------------------------------------------ MFMA kernel
 template <int BM, int BN, bool CONV>
@@ -339,6 +255,10 @@ __global__ void gemm_naive_kernel(GemmDev p)
 }
 
 // ------------------------------------------------------------------------------------------ host side
+struct GemmDev;
+bool gemm_big_supported(const GemmArgs& a);                                        // gemm_big.hip
+void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
+
 int gemm_npad(int N) { return (N % 160 == 0 || N % 128 == 0) ? N : round_up(N, 128); }
 
 static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
@@ -409,6 +329,28 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     GemmDev p = to_dev(ctx, a);
     const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
     const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (a.R ? 2 : 1)) * 2.0 * a.batch;
+    static const int big_env = getenv("SDE_BIG") ? atoi(getenv("SDE_BIG")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
+    if (!ctx.force_naive && big_env && gemm_big_supported(a)) {
+        // 8-wave 256x320 tiles, one block per CU: worth it once the grid (with split-K on long K) covers most of the chip
+        const int tiles = cdiv(a.M, 256) * (a.Npad / 320) * a.batch, nk = a.K >> 6;
+        int sk = 1;
+        if (a.batch == 1 && ctx.splitk_ws && tiles < 192 && nk >= 64) {
+            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 32), 4);
+            if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
+            while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > ctx.splitk_ws_bytes) --sk;
+        }
+        if (big_env == 2 || ctx.force_big || tiles * sk >= 192) {
+            ProfScope ps(ctx, a.taps == 9 ? "conv3x3_mfma" : "gemm_mfma", flops, bytes);
+            p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
+            launch_gemm_big(ctx, p, a.batch, a.taps == 9);
+            if (sk > 1) {
+                long long total = (long long)p.M * (p.Npad >> 2);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);
+            }
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     if (!ctx.force_naive && gemm_mfma_supported(a)) {
         ProfScope ps(ctx, a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU ? "gemm_geglu_mfma" : "gemm_mfma"), flops, bytes);
         // tile height: 128 rows unless that leaves the chip (256 CUs x 2 blocks) under-filled and split-K (<= 4 ways,

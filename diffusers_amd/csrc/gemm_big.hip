@@ -1,0 +1,298 @@
+// gemm_big.hip — 8-wave 256x320x64 "ping-pong" fp16 GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+// Same contract as gemm.hip (D = epilogue(A * W^T), A through an implicit im2col), for the large MFMA-bound shapes
+// of the UNet (3x3 convs and wide linears with N % 320 == 0).  Why a second kernel: with 128x160 tiles the
+// global->LDS path (64 B/clk/CU) is ~90 % busy per MFMA-bound K step; a 256x320 tile brings that to 45 %.
+//
+// Structure:
+//   * 512 threads = 8 waves as 2 (M) x 4 (N); each wave owns a 128 x 80 sub-tile = 8 x 5 MFMA 16x16x32 tiles
+//     (160 accumulator VGPRs), issued as D^T = W * A^T so a lane holds 4 consecutive n of one m.
+//   * LDS: 2 K-tile buffers x (256 + 320) rows x 128 B = 144 KiB, filled by buffer_load_dwordx4 ... lds
+//     (lane-linear image, XOR swizzle on the source chunk, same XOR on the ds_read_b128 address).  Padded taps and
+//     tail rows use the buffer descriptor's range check (offset >= num_records returns zeros): no zero page, no
+//     64-bit address arithmetic.
+//   * Each K-tile is 4 phases (m-half x k-half) of {ds_read fragments, issue loads | barrier | 20 MFMA | barrier}.
+//     Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA section while its
+//     partner is in its load section.  Loads for K-tile t+1 are spread over the sections of tile t and retired with
+//     one s_waitcnt vmcnt(0) per tile placed two sections after the last issue (never right behind an issue).
+//   * XCD-aware bijective block remap, optional split-K (partial fp32 slabs reduced by gemm.hip's reduce kernel).
+#include "gemm_common.h"
+
+#include <algorithm>
+
+namespace {
+constexpr int BM = 256, BN = 320;
+constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 73,728 B per K-tile
+constexpr int SMEM_BYTES = 2 * STAGE;                                               // 147,456 B
+constexpr int NPA = BM / 64, NPB = BN / 64, NPART = NPA + NPB;                      // 64-row staging parts: 4 + 5
+constexpr unsigned OOB = 0x80000000u;                                               // >= num_records -> reads as zero
+constexpr int RSRC_FLAGS = 0x00020000;
+
+}  // namespace
+
+template <bool CONV>
+__global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // loads issued per section for the next K-tile; sections are L0 M0 L1 M1 L2 M2 L3 M3 (L = load, M = MFMA section).
+    // Waves 0-3 may not touch the other buffer before M0 (waves 4-7 are still reading it during L0).
+    constexpr int kSched[2][8] = {
+        {0, 2, 2, 1, 2, 2, 0, 0},   // waves 0-3
+        {3, 1, 2, 1, 2, 0, 0, 0},   // waves 4-7
+    };
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 2, wc = wid & 3;
+    const int z = blockIdx.z;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    // XCD-aware bijective remap (blocks b, b+8, ... share an XCD/L2): each XCD gets a contiguous range of tiles
+    const int nwg = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid / p.nbn, tn = bid - tm * p.nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk_all = p.K >> 6;
+    const int ks = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * ks / p.splitk);
+    const int nk = (int)((long long)nk_all * (ks + 1) / p.splitk) - kt0;
+
+    // buffer descriptors (raw, 2 GiB window; padded taps / tail rows use offset OOB)
+    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A0 + z * p.sA), 0, OOB, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((p.A1 ? p.A1 : p.A0) + z * p.sA), 0, OOB, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + z * p.sW), 0, OOB, RSRC_FLAGS);
+
+    // ---- staging geometry: part j covers rows [64j, 64j+64) of the A tile (j < 4) or of the W tile (j >= 4);
+    //      wave w stages rows 8w..8w+7 of the part, lane -> (row = lane>>3, 16-B chunk = (lane&7) ^ row)
+    const int srow = lane >> 3;
+    const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
+    int a_pix[NPA];        // source pixel index of the window centre (conv) / row index (linear)
+    unsigned a_mask[NPA];  // bit t: tap t in bounds (and row < M); bits 9,10: oy,ox parity (fused 2x upsample)
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int m = m0 + j * 64 + wid * 8 + srow;
+        const bool ok = m < p.M;
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int nb = m / hw, rem = m - nb * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int cy = oy * p.stride, cx = ox * p.stride;   // window centre in the (virtual) input
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                if (ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mask |= 1u << t;
+            }
+            mask |= (unsigned)(cy & 1) << 9 | (unsigned)(cx & 1) << 10;
+            a_mask[j] = mask;
+            a_pix[j] = nb * p.Hs * p.Ws + (cy >> p.ups) * p.Ws + (cx >> p.ups);
+        } else {
+            a_mask[j] = ok ? 1u : 0u;
+            a_pix[j] = m;
+        }
+    }
+    const unsigned w_off = (unsigned)((n0 + wid * 8 + srow) * p.K) * 2u + lchunk16;
+    const int Ctot = p.C0 + p.C1;
+
+    // staging state of the K-tile currently being issued (wave-uniform)
+    int st_k0 = kt0 << 6, st_tap = 0, st_c = st_k0;
+    if (CONV) { st_tap = st_k0 / Ctot; st_c = st_k0 - st_tap * Ctot; }
+    auto stage_advance = [&]() {
+        st_k0 += 64; st_c += 64;
+        if (CONV && st_c >= Ctot) { st_c = 0; ++st_tap; }
+    };
+    // issue staging part j of the current staging K-tile into buffer `buf`
+    auto issue = [&](int j, int buf) {
+        char* dst = smem + buf * STAGE + (j < NPA ? j * 8192 : A_BYTES + (j - NPA) * 8192) + wid * 1024;
+        if (j < NPA) {
+            const bool second = st_c >= p.C0;
+            const int ld2 = (second ? p.lda1 : p.lda0) * 2;
+            const unsigned cc2 = (unsigned)(second ? st_c - p.C0 : st_c) * 2u + lchunk16;
+            int delta = 0;
+            if (CONV) {
+                const int dy = st_tap / 3, dx = st_tap - dy * 3;
+                if (p.ups) {
+                    const int ey = (a_mask[j] >> 9) & 1 ? (dy == 2) : -(dy == 0);
+                    const int ex = (a_mask[j] >> 10) & 1 ? (dx == 2) : -(dx == 0);
+                    delta = ey * p.Ws + ex;
+                } else {
+                    delta = (dy - 1) * p.Ws + (dx - 1);
+                }
+            }
+            const bool valid = (a_mask[j] >> st_tap) & 1;
+            const unsigned voff = valid ? (unsigned)__umul24((unsigned)(a_pix[j] + delta), (unsigned)ld2) + cc2 : OOB;
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, LDS_PTR(dst), 16, voff, 0, 0, 0);
+            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
+        } else {
+            const int soff = (j - NPA) * 128 * p.K + st_k0 * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, soff, 0, 0);
+        }
+    };
+
+    // ---- fragment read addresses (swizzled): A rows wr*128 + mt*16 + fr, W rows wc*80 + nt*16 + fr
+    const int swz0 = ((fg) ^ (fr & 7)) << 4, swz1 = ((4 + fg) ^ (fr & 7)) << 4;
+    const int a_rd0 = (wr * 128 + fr) * 128 + swz0, a_rd1 = (wr * 128 + fr) * 128 + swz1;
+    const int b_rd0 = A_BYTES + (wc * 80 + fr) * 128 + swz0, b_rd1 = A_BYTES + (wc * 80 + fr) * 128 + swz1;
+
+    floatx4 acc[5][8];
+#pragma unroll
+    for (int a = 0; a < 5; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 bf[5], af[4];
+
+    // ---- prologue: K-tile 0 into buffer 0
+#pragma unroll
+    for (int j = 0; j < NPART; ++j) issue(j, 0);
+    stage_advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+
+#define LOAD_B(ofs)                                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < 5; ++nt) bf[nt] = *(const half8*)(cur + (ofs) + nt * 2048);
+#define LOAD_A(ofs, mh)                                                                               \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) af[mt] = *(const half8*)(cur + (ofs) + ((mh) * 4 + mt) * 2048);
+#define ISSUE_N(sec)                                                                                  \
+    if (more) {                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < kSched[0][sec]; ++i) if (wr == 0) issue(jn0 + i, nb_);   \
+        _Pragma("unroll") for (int i = 0; i < kSched[1][sec]; ++i) if (wr == 1) issue(jn1 + i, nb_);   \
+    }                                                                                                 \
+    jn0 += kSched[0][sec]; jn1 += kSched[1][sec];
+#define MFMA_BLOCK(mh)                                                                                \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < 5; ++nt)                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
+            acc[nt][(mh) * 4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[nt][(mh) * 4 + mt], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* cur = smem + (kt & 1) * STAGE;
+        const int nb_ = (kt & 1) ^ 1;
+        const bool more = kt + 1 < nk;
+        int jn0 = 0, jn1 = 0;
+        // phase 0: (m-half 0, k-half 0)
+        LOAD_B(b_rd0) LOAD_A(a_rd0, 0)
+        ISSUE_N(0)
+        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        ISSUE_N(1)
+        MFMA_BLOCK(0)
+        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        // phase 1: (m-half 1, k-half 0)
+        LOAD_A(a_rd0, 1)
+        ISSUE_N(2)
+        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        ISSUE_N(3)
+        MFMA_BLOCK(1)
+        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        // phase 2: (m-half 1, k-half 1)
+        LOAD_B(b_rd1) LOAD_A(a_rd1, 1)
+        ISSUE_N(4)
+        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        ISSUE_N(5)
+        MFMA_BLOCK(1)
+        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        // phase 3: (m-half 0, k-half 1)
+        LOAD_A(a_rd1, 0)
+        FENCE();
+        if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves 4-7: last issue was in L2, two sections ago
+        __builtin_amdgcn_s_barrier(); FENCE();
+        MFMA_BLOCK(0)
+        FENCE();
+        if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves 0-3: last issue was in M2, two sections ago
+        __builtin_amdgcn_s_barrier(); FENCE();
+        if (more) stage_advance();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7
+#undef LOAD_B
+#undef LOAD_A
+#undef ISSUE_N
+#undef MFMA_BLOCK
+#undef FENCE
+
+    // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*128 + mt*16 + fr
+    const long long zD = z * p.sD, zR = z * p.sR;
+    if (p.splitk > 1) {
+        float* ws = p.ws + (long long)ks * p.M * p.Npad;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wr * 128 + mt * 16 + fr;
+            if (m < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
+                    *(floatx4*)(ws + (long long)m * p.Npad + n) = acc[nt][mt];
+                }
+            }
+        }
+        return;
+    }
+    {   // EPI_STD with N % 4 == 0 (checked on the host), one row group at a time so the 160 accumulators stay in registers
+        float bv[5][4];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
+        }
+        const half_t* R = p.R ? p.R + zR : nullptr;
+        half_t* D = p.D + zD;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wr * 128 + mt * 16 + fr;
+            if (m < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
+                    if (n < p.N) {
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
+                        if (R) {
+                            const half4 rr = *(const half4*)(R + (long long)m * p.ldr + n);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] += (float)rr[r];
+                        }
+                        const half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                        *(half4*)(D + (long long)m * p.ldd + n) = h;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+bool gemm_big_supported(const GemmArgs& a)
+{
+    if (!gemm_mfma_supported(a)) return false;
+    if (a.Npad % BN || a.epi != EPI_STD || (a.N & 3)) return false;   // other epilogues stay on gemm.hip's kernel
+    // 32-bit byte offsets inside a 2 GiB descriptor window; 24-bit pixel index / row pitch for the mad
+    const long long rowsA = a.taps == 9 ? (long long)(a.M / (a.Ho * a.Wo)) * (a.ups ? (a.Hi / 2) * (a.Wi / 2) : a.Hi * a.Wi) : a.M;
+    if (rowsA >= (1 << 24) || a.lda0 * 2 >= (1 << 24) || a.lda1 * 2 >= (1 << 24)) return false;
+    if (rowsA * std::max(a.lda0, a.lda1) * 2 >= 0x7ff00000LL) return false;
+    if ((long long)a.Npad * a.K * 2 >= 0x7ff00000LL) return false;
+    return true;
+}
+
+void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        attr_set = true;
+    }
+    p.nbm = cdiv(p.M, BM);
+    p.nbn = p.Npad / BN;
+    dim3 grid(p.nbm * p.nbn, p.splitk, batch);
+    if (conv) hipLaunchKernelGGL(gemm_big_kernel<true>, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+    else      hipLaunchKernelGGL(gemm_big_kernel<false>, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+}

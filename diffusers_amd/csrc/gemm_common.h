@@ -1,0 +1,91 @@
+// gemm_common.h — device-side argument block and the shared epilogue of the GEMM / implicit-GEMM conv kernels
+// (gemm.hip: 4-wave 128/64-row tiles; gemm_big.hip: 8-wave 256x320 ping-pong tiles).
+#pragma once
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+struct GemmDev {
+    const half_t* A0; const half_t* A1;
+    int C0, C1, lda0, lda1;
+    int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws;
+    const half_t* W; int Npad;
+    const float* bias; const half_t* R; int ldr;
+    half_t* D; float* Df; int ldd; int epi; float alpha;
+    long long sA, sW, sD, sR;
+    const half_t* zeros;
+    int nbm, nbn;
+    int splitk; float* ws;   // splitk > 1: raw fp32 partial tiles go to ws[ks][M][Npad], reduced by splitk_reduce_kernel
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// ------------------------------------------------------------------------------------------ epilogue (shared)
+// Handles 4 consecutive columns n..n+3 of row m held in v[0..3].
+__device__ __forceinline__ void epilogue4(const GemmDev& p, int m, int n, floatx4 v, floatx4 vg, long long zD, long long zR)
+{
+    if (m >= p.M) return;
+    if (p.epi == EPI_STD) {
+        if (n >= p.N) return;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = v[r] * p.alpha;
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) o[r] += p.bias[n + r];
+        }
+        if (n + 3 < p.N) {
+            if (p.R) {
+                half4 rr = *(const half4*)(p.R + zR + (long long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] += (float)rr[r];
+            }
+            half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                float x = o[r];
+                if (p.R) x += (float)p.R[zR + (long long)m * p.ldr + n + r];
+                p.D[zD + (long long)m * p.ldd + n + r] = (half_t)x;
+            }
+        }
+    } else if (p.epi == EPI_GEGLU) {
+        // v = value columns, vg = gate columns for output columns j..j+3 (j passed in n)
+        int half_n = p.N >> 1;
+        if (n >= half_n) return;
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = v[r], g = vg[r];
+            if (p.bias && n + r < half_n) { a += p.bias[n + r]; g += p.bias[half_n + n + r]; }
+            h[r] = (half_t)(a * gelu_erf(g));
+        }
+        if (n + 3 < half_n) *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
+        else for (int r = 0; r < 4 && n + r < half_n; ++r) p.D[zD + (long long)m * p.ldd + n + r] = h[r];
+    } else if (p.epi == EPI_NCHW_F32) {
+        int hw = p.Ho * p.Wo;
+        int nb = m / hw, pix = m - nb * hw;
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r] + (p.bias ? p.bias[n + r] : 0.f);
+            p.Df[zD + ((long long)nb * p.N + n + r) * hw + pix] = x;
+        }
+    } else if (p.epi == EPI_IMAGE) {
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r] + (p.bias ? p.bias[n + r] : 0.f);
+            x = x / 2.0f + 0.5f;
+            x = fminf(fmaxf(x, 0.0f), 1.0f);
+            p.Df[zD + (long long)m * p.N + n + r] = x;
+        }
+    } else {  // EPI_TRANS
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r] * p.alpha + (p.bias ? p.bias[n + r] : 0.f);
+            p.D[zD + (long long)(n + r) * p.ldd + m] = (half_t)x;
+        }
+    }
+}
+
