@@ -18,105 +18,156 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 // ------------------------------------------------------------------------------------------ GroupNorm
-// Pass 1: per (image, pixel-chunk) partial per-channel sums -> per-group partial sums.
-//   thread layout: TPP threads across the channel octets of one pixel (each OPT octets), PR pixel rows per block.
-// ws layout: part[NB][nchunks][groups][2] | ab[NB][C][2]
+// Two launches, both HBM-bound (x is read twice, y written once):
+//   gn_stats_kernel : per (image, pixel-chunk) partial sums per group           -> part[NB][nchunks][groups][2]
+//   gn_apply_kernel : each block first folds the partials of its image into per-channel scale/shift in LDS
+//                     (a = rstd*gamma, b = beta - mean*a), then streams y = x*a + b (+SiLU) over its rows.
+// No atomics anywhere: the reduction order is fixed, results are run-to-run deterministic.
+//   thread layout of the stats pass: TPP threads across the channel octets of one pixel (each OPT octets), PR pixel rows.
 #define GN_MAX_OPT 4
-__global__ void gn_stats_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, int groups, int TPP, int OPT,
-                                int PR, int ppc, int nchunks, float* part)
+#define GN_U 8   // pixels per trip: GN_U*OPT 16-byte loads in flight per thread (the pass is latency-bound otherwise)
+template <int OPT>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, int groups, int TPP,
+                                                       int PR, int ppc, int nchunks, float* part)
 {
-    extern __shared__ float sh[];  // [PR][C] sums | [PR][C] sumsq  (no atomics: results are run-to-run deterministic)
+    extern __shared__ float sh[];  // [PR][C] sums | [PR][C] sumsq
     const int C = C0 + C1;
     const int nb = blockIdx.y, chunk = blockIdx.x;
     const int tid = threadIdx.x;
     const int cx = tid % TPP, pr = tid / TPP;
-    float s[GN_MAX_OPT][8], q[GN_MAX_OPT][8];
+    const bool active = pr < PR;
+    float s[OPT][8], q[OPT][8];
 #pragma unroll
-    for (int o = 0; o < GN_MAX_OPT; ++o)
+    for (int o = 0; o < OPT; ++o)
 #pragma unroll
         for (int j = 0; j < 8; ++j) { s[o][j] = 0.f; q[o][j] = 0.f; }
     const int p_begin = chunk * ppc, p_end = min(HW, p_begin + ppc);
-    for (int px = p_begin + pr; px < p_end; px += PR) {
-        const long long row = (long long)nb * HW + px;
+    if (active) {
+        for (int px = p_begin + pr; px < p_end; px += GN_U * PR) {
+            half8 v[GN_U][OPT];
 #pragma unroll
-        for (int o = 0; o < GN_MAX_OPT; ++o) {
-            if (o < OPT) {
-                int c = (cx + o * TPP) * 8;
-                const half_t* src = c < C0 ? X0 + row * C0 + c : X1 + row * C1 + (c - C0);
-                half8 v = *(const half8*)src;
+            for (int u = 0; u < GN_U; ++u) {
+                const int pp = px + u * PR;
+                const long long row = (long long)nb * HW + min(pp, p_end - 1);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float f = (float)v[j]; s[o][j] += f; q[o][j] += f * f; }
+                for (int o = 0; o < OPT; ++o) {
+                    int c = (cx + o * TPP) * 8;
+                    const half_t* src = c < C0 ? X0 + row * C0 + c : X1 + row * C1 + (c - C0);
+                    v[u][o] = *(const half8*)src;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < GN_U; ++u) {
+                if (px + u * PR < p_end) {
+#pragma unroll
+                    for (int o = 0; o < OPT; ++o) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { float f = (float)v[u][o][j]; s[o][j] += f; q[o][j] += f * f; }
+                    }
+                }
             }
         }
     }
-    float* shs = sh + (size_t)pr * C;
-    float* shq = sh + (size_t)PR * C + (size_t)pr * C;
+    if (active) {
+        float* shs = sh + (size_t)pr * C;
+        float* shq = sh + (size_t)PR * C + (size_t)pr * C;
 #pragma unroll
-    for (int o = 0; o < GN_MAX_OPT; ++o) {
-        if (o < OPT) {
+        for (int o = 0; o < OPT; ++o) {
             int c = (cx + o * TPP) * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { shs[c + j] = s[o][j]; shq[c + j] = q[o][j]; }
         }
     }
     __syncthreads();
-    const int cpg = C / groups;
-    for (int g = tid; g < groups; g += blockDim.x) {
+    // fold the PR pixel rows: one thread per channel, result in row 0
+    for (int c = tid; c < C; c += blockDim.x) {
         float a = 0.f, b = 0.f;
-        for (int r = 0; r < PR; ++r)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += sh[(size_t)r * C + c]; b += sh[(size_t)PR * C + (size_t)r * C + c]; }
-        float* dst = part + (((long long)nb * nchunks + chunk) * groups + g) * 2;
-        dst[0] = a; dst[1] = b;
-    }
-}
-
-// Pass 2: reduce partials -> mean / rstd per group -> per-channel scale a = rstd*gamma, shift b = beta - mean*a.
-__global__ void gn_finalize_kernel(const float* part, int nchunks, int groups, int C, int HW, float eps, const float* gamma,
-                                   const float* beta, float* ab)
-{
-    const int nb = blockIdx.x;
-    __shared__ float smean[64], srstd[64];
-    const int cpg = C / groups;
-    for (int g = threadIdx.x; g < groups; g += blockDim.x) {
-        float a = 0.f, b = 0.f;
-        for (int ch = 0; ch < nchunks; ++ch) {
-            const float* src = part + (((long long)nb * nchunks + ch) * groups + g) * 2;
-            a += src[0]; b += src[1];
-        }
-        float cnt = (float)cpg * (float)HW;
-        float mean = a / cnt;
-        float var = fmaxf(b / cnt - mean * mean, 0.f);
-        smean[g] = mean; srstd[g] = rsqrtf(var + eps);
+        for (int r = 0; r < PR; ++r) { a += sh[(size_t)r * C + c]; b += sh[(size_t)PR * C + (size_t)r * C + c]; }
+        sh[c] = a; sh[(size_t)PR * C + c] = b;
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        int g = c / cpg;
-        float a = srstd[g] * gamma[c];
-        ab[((long long)nb * C + c) * 2] = a;
-        ab[((long long)nb * C + c) * 2 + 1] = beta[c] - smean[g] * a;
+    // 8 lanes per group (groups <= 32 per pass of 256 threads)
+    const int cpg = C / groups;
+    for (int g0 = 0; g0 < groups; g0 += 32) {
+        const int g = g0 + (tid >> 3), sub = tid & 7;
+        float a = 0.f, b = 0.f;
+        if (g < groups)
+            for (int c = g * cpg + sub; c < (g + 1) * cpg; c += 8) { a += sh[c]; b += sh[(size_t)PR * C + c]; }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (g < groups && sub == 0) {
+            float* dst = part + (((long long)nb * nchunks + chunk) * groups + g) * 2;
+            dst[0] = a; dst[1] = b;
+        }
     }
 }
 
-// Pass 3: y = x*a + b (+SiLU); writes the concatenated tensor.
-__global__ void gn_apply_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, long long total_oct, const float* ab,
-                                int silu, half_t* Y)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, int rows_per_block,
+                                                       const float* part, int nchunks, int groups, float eps, const float* gamma,
+                                                       const float* beta, int silu, half_t* Y)
 {
+    extern __shared__ float sh[];   // ab[C][2] | mean[groups] | rstd[groups]
     const int C = C0 + C1, CX = C >> 3;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total_oct; i += (long long)gridDim.x * blockDim.x) {
-        long long row = i / CX;
-        int c = (int)(i - row * CX) * 8;
-        int nb = (int)(row / HW);
-        const half_t* src = c < C0 ? X0 + row * C0 + c : X1 + row * C1 + (c - C0);
-        half8 v = *(const half8*)src;
-        const float* abp = ab + ((long long)nb * C + c) * 2;
-        half8 o;
+    const int nb = blockIdx.y, tid = threadIdx.x;
+    float* ab = sh;
+    float* smean = sh + 2 * C;
+    float* srstd = smean + groups;
+    const int cpg = C / groups;
+    for (int g0 = 0; g0 < groups; g0 += 32) {
+        const int g = g0 + (tid >> 3), sub = tid & 7;
+        float a = 0.f, b = 0.f;
+        if (g < groups)
+            for (int ch = sub; ch < nchunks; ch += 8) {
+                const float* src = part + (((long long)nb * nchunks + ch) * groups + g) * 2;
+                a += src[0]; b += src[1];
+            }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float y = (float)v[j] * abp[2 * j] + abp[2 * j + 1];
-            if (silu) y = y / (1.0f + __expf(-y));
-            o[j] = (half_t)y;
+        for (int o = 4; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (g < groups && sub == 0) {
+            const float cnt = (float)cpg * (float)HW;
+            const float mean = a / cnt;
+            const float var = fmaxf(b / cnt - mean * mean, 0.f);
+            smean[g] = mean; srstd[g] = rsqrtf(var + eps);
         }
-        *(half8*)(Y + row * C + c) = o;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float a = srstd[g] * gamma[c];
+        ab[2 * c] = a; ab[2 * c + 1] = beta[c] - smean[g] * a;
+    }
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
+    const long long base_row = (long long)nb * HW;
+    const int total = (r1 - r0) * CX;
+    // 4 octets per trip: all loads first, so 4 x 16 B per thread are in flight
+    for (int i0 = tid; i0 < total; i0 += 4 * blockDim.x) {
+        half8 v[4];
+        int cc[4]; long long rw[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + u * (int)blockDim.x, total - 1);
+            const int rr = i / CX;
+            cc[u] = (i - rr * CX) * 8;
+            rw[u] = base_row + r0 + rr;
+            const half_t* src = cc[u] < C0 ? X0 + rw[u] * C0 + cc[u] : X1 + rw[u] * C1 + (cc[u] - C0);
+            v[u] = *(const half8*)src;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u * (int)blockDim.x < total) {
+                const float4* abp = (const float4*)(ab + 2 * cc[u]);
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 t = abp[j];
+                    float y0 = (float)v[u][2 * j] * t.x + t.y, y1 = (float)v[u][2 * j + 1] * t.z + t.w;
+                    if (silu) { y0 = y0 / (1.0f + __expf(-y0)); y1 = y1 / (1.0f + __expf(-y1)); }
+                    o[2 * j] = (half_t)y0; o[2 * j + 1] = (half_t)y1;
+                }
+                *(half8*)(Y + rw[u] * C + cc[u]) = o;
+            }
+        }
     }
 }
 
@@ -127,7 +178,7 @@ static void gn_geometry(int C, int HW, int& TPP, int& OPT, int& PR, int& ppc, in
     while (CX % OPT) ++OPT;
     TPP = CX / OPT;
     PR = std::max(1, 256 / TPP);
-    // aim for ~1024 blocks per launch across the batch, at least 64 pixels per chunk
+    // <= 64 pixel chunks per image, at least 64 pixels each
     ppc = std::max(64, cdiv(HW, 64));
     ppc = std::min(ppc, HW);
     nchunks = cdiv(HW, ppc);
@@ -137,7 +188,7 @@ size_t groupnorm_ws_floats(int NB, int C, int HW)
 {
     int TPP, OPT, PR, ppc, nchunks;
     gn_geometry(C, HW, TPP, OPT, PR, ppc, nchunks);
-    return (size_t)NB * nchunks * 64 * 2 + (size_t)NB * C * 2;
+    return (size_t)NB * nchunks * 64 * 2;
 }
 
 void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
@@ -149,72 +200,90 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
     gn_geometry(C, a.HW, TPP, OPT, PR, ppc, nchunks);
     SDE_REQUIRE(OPT <= GN_MAX_OPT, SDE_ERR_INVALID_ARGUMENT, "groupnorm: too many channels");
     float* part = a.ws;
-    float* ab = a.ws + (size_t)a.NB * nchunks * 64 * 2;
     const double bytes = (double)a.NB * a.HW * C * 2.0;
     {
         ProfScope ps(ctx, "groupnorm_stats", 0, bytes);
-        hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, a.NB), dim3(TPP * PR), (size_t)2 * PR * C * sizeof(float), ctx.stream, a.X0, a.X1, a.C0,
-                           a.C1, a.HW, a.groups, TPP, OPT, PR, ppc, nchunks, part);
-    }
-    {
-        ProfScope ps(ctx, "groupnorm_finalize", 0, 0);
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.NB), dim3(256), 0, ctx.stream, part, nchunks, a.groups, C, a.HW, a.eps, a.gamma,
-                           a.beta, ab);
+        const dim3 grid(nchunks, a.NB), block(256);
+        const size_t lds = (size_t)2 * PR * C * sizeof(float);
+#define GN_STATS(O) hipLaunchKernelGGL(gn_stats_kernel<O>, grid, block, lds, ctx.stream, a.X0, a.X1, a.C0, a.C1, a.HW, a.groups, TPP, PR, ppc, nchunks, part)
+        if (OPT == 1) GN_STATS(1); else if (OPT == 2) GN_STATS(2); else if (OPT == 3) GN_STATS(3); else GN_STATS(4);
+#undef GN_STATS
     }
     {
         ProfScope ps(ctx, a.silu ? "groupnorm_silu_apply" : "groupnorm_apply", 0, 2 * bytes);
-        long long total = (long long)a.NB * a.HW * (C / 8);
-        int blocks = (int)std::min<long long>(cdiv64(total, 256), 256 * 16);
-        hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, ctx.stream, a.X0, a.X1, a.C0, a.C1, a.HW, total, ab,
-                           a.silu ? 1 : 0, a.Y);
+        // ~1024 blocks across the batch, at least 16 pixel rows each
+        int bpi = std::max(1, std::min(cdiv(1024, a.NB), cdiv(a.HW, 16)));
+        const int rpb = cdiv(a.HW, bpi);
+        bpi = cdiv(a.HW, rpb);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, a.NB), dim3(256), (size_t)(2 * C + 2 * a.groups) * sizeof(float), ctx.stream, a.X0, a.X1,
+                           a.C0, a.C1, a.HW, rpb, part, nchunks, a.groups, a.eps, a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
     }
     HIP_CHECK(hipGetLastError());
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm
-// one wave per row; the row lives in registers (<= LN_MAX_OCT octets per lane) for an exact two-pass variance.
+// one wave per LN_ROWS rows; the rows live in registers (<= LN_MAX_OCT octets per lane and row) for an exact two-pass
+// variance.  All loads of the wave's rows are issued before the first reduction (memory-level parallelism).
 #define LN_MAX_OCT 4
-__global__ void layernorm_kernel(const half_t* X, half_t* Y, int rows, int C, const float* gamma, const float* beta, float eps)
+#define LN_ROWS 4
+template <int NOCT>
+__global__ __launch_bounds__(256) void layernorm_kernel(const half_t* X, half_t* Y, int rows, int C, const float* gamma, const float* beta, float eps)
 {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LN_ROWS;
+    if (row0 >= rows) return;
     const int CX = C >> 3;
-    const half_t* x = X + (long long)row * C;
-    half8 v[LN_MAX_OCT];
-    float sum = 0.f;
+    half8 v[LN_ROWS][NOCT];
 #pragma unroll
-    for (int o = 0; o < LN_MAX_OCT; ++o) {
-        int cx = lane + o * 64;
-        if (cx < CX) {
-            v[o] = *(const half8*)(x + cx * 8);
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const half_t* x = X + (long long)min(row0 + r, rows - 1) * C;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += (float)v[o][j];
+        for (int o = 0; o < NOCT; ++o) {
+            const int cx = lane + o * 64;
+            if (cx < CX) v[r][o] = *(const half8*)(x + cx * 8);
         }
     }
-    const float mean = wave_sum(sum) / (float)C;
-    float sq = 0.f;
+    float g[NOCT][8], bta[NOCT][8];
 #pragma unroll
-    for (int o = 0; o < LN_MAX_OCT; ++o) {
-        int cx = lane + o * 64;
+    for (int o = 0; o < NOCT; ++o) {
+        const int cx = lane + o * 64;
         if (cx < CX) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float dlt = (float)v[o][j] - mean; sq += dlt * dlt; }
+            for (int j = 0; j < 8; ++j) { g[o][j] = gamma[cx * 8 + j]; bta[o][j] = beta[cx * 8 + j]; }
         }
     }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
-    half_t* y = Y + (long long)row * C;
 #pragma unroll
-    for (int o = 0; o < LN_MAX_OCT; ++o) {
-        int cx = lane + o * 64;
-        if (cx < CX) {
-            half8 out;
+    for (int r = 0; r < LN_ROWS; ++r) {
+        float sum = 0.f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int c = cx * 8 + j;
-                out[j] = (half_t)(((float)v[o][j] - mean) * rstd * gamma[c] + beta[c]);
+        for (int o = 0; o < NOCT; ++o) {
+            if (lane + o * 64 < CX) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += (float)v[r][o][j];
             }
-            *(half8*)(y + cx * 8) = out;
+        }
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) {
+            if (lane + o * 64 < CX) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float dlt = (float)v[r][o][j] - mean; sq += dlt * dlt; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        if (row0 + r < rows) {
+            half_t* y = Y + (long long)(row0 + r) * C;
+#pragma unroll
+            for (int o = 0; o < NOCT; ++o) {
+                const int cx = lane + o * 64;
+                if (cx < CX) {
+                    half8 out;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) out[j] = (half_t)(((float)v[r][o][j] - mean) * rstd * g[o][j] + bta[o][j]);
+                    *(half8*)(y + cx * 8) = out;
+                }
+            }
         }
     }
 }
@@ -223,7 +292,12 @@ void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows
 {
     SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
     ProfScope ps(ctx, "layernorm", 0, 4.0 * rows * C);
-    hipLaunchKernelGGL(layernorm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
+    const int noct = cdiv(C / 8, 64);
+    const dim3 grid(cdiv(rows, 4 * LN_ROWS)), block(256);
+    if (noct == 1)      hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
+    else if (noct == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
+    else if (noct == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
+    else                hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
     HIP_CHECK(hipGetLastError());
 }
 
