@@ -318,6 +318,17 @@ static void launch_mfma(const LaunchCtx& ctx, GemmDev& p, int batch)
     }
 }
 
+// profiler class name; SDE_PROF_SHAPES=1 appends the problem shape (tools/shape_profile.py)
+static const char* prof_name(const char* base, const GemmArgs& a, const char* kern)
+{
+    static const bool shapes = getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"));
+    if (!shapes) return base;
+    static thread_local char buf[48];
+    snprintf(buf, sizeof(buf), "%s%s M%d N%d K%d%s%s", a.taps == 9 ? "c3" : (a.epi == EPI_GEGLU ? "gg" : "g1"), kern, a.M, a.N, a.K,
+             a.R ? " R" : "", a.batch > 1 ? " b" : "");
+    return buf;
+}
+
 void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
 {
     SDE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.A0 && a.W, SDE_ERR_INVALID_ARGUMENT, "launch_gemm: empty problem");
@@ -335,12 +346,12 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         const int tiles = cdiv(a.M, 256) * (a.Npad / 320) * a.batch, nk = a.K >> 6;
         int sk = 1;
         if (a.batch == 1 && ctx.splitk_ws && tiles < 192 && nk >= 64) {
-            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 32), 4);
+            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 32), 2);   // deeper splits: the 4-wave kernel's slabs are cheaper
             if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
-            while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > ctx.splitk_ws_bytes) --sk;
+            while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;   // slab traffic must stay small next to the GEMM
         }
         if (big_env == 2 || ctx.force_big || tiles * sk >= 192) {
-            ProfScope ps(ctx, a.taps == 9 ? "conv3x3_mfma" : "gemm_mfma", flops, bytes);
+            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma" : "gemm_mfma", a, "B"), flops, bytes);
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
             launch_gemm_big(ctx, p, a.batch, a.taps == 9);
             if (sk > 1) {
@@ -352,7 +363,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         }
     }
     if (!ctx.force_naive && gemm_mfma_supported(a)) {
-        ProfScope ps(ctx, a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU ? "gemm_geglu_mfma" : "gemm_mfma"), flops, bytes);
+        ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU ? "gemm_geglu_mfma" : "gemm_mfma"), a, "S"), flops, bytes);
         // tile height: 128 rows unless that leaves the chip (256 CUs x 2 blocks) under-filled and split-K (<= 4 ways,
         // long K only) cannot make up for it -> 64 rows.  Measured on MI355X at UNet batch 16 (tools/microbench.py).
         static const int bm64_env = getenv("SDE_BM64") ? atoi(getenv("SDE_BM64")) : -1;   // tuning hook

@@ -243,24 +243,40 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         }
         const half_t* R = p.R ? p.R + zR : nullptr;
         half_t* D = p.D + zD;
+        // two halves of 4 row groups: the 20 residual loads of a half are all in flight before the first use
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = m0 + wr * 128 + mt * 16 + fr;
-            if (m < p.M) {
+        for (int mh = 0; mh < 2; ++mh) {
+            half4 rr[4][5];
+            if (R) {
 #pragma unroll
-                for (int nt = 0; nt < 5; ++nt) {
-                    const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
-                    if (n < p.N) {
-                        float o[4];
+                for (int mq = 0; mq < 4; ++mq) {
+                    const int m = min(m0 + wr * 128 + (mh * 4 + mq) * 16 + fr, p.M - 1);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
-                        if (R) {
-                            const half4 rr = *(const half4*)(R + (long long)m * p.ldr + n);
+                    for (int nt = 0; nt < 5; ++nt) {
+                        const int n = min(n0 + wc * 80 + nt * 16 + 4 * fg, p.N - 4);
+                        rr[mq][nt] = *(const half4*)(R + (long long)m * p.ldr + n);
+                    }
+                }
+            }
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] += (float)rr[r];
+            for (int mq = 0; mq < 4; ++mq) {
+                const int mt = mh * 4 + mq;
+                const int m = m0 + wr * 128 + mt * 16 + fr;
+                if (m < p.M) {
+#pragma unroll
+                    for (int nt = 0; nt < 5; ++nt) {
+                        const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
+                        if (n < p.N) {
+                            float o[4];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
+                            if (R) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) o[r] += (float)rr[mq][nt][r];
+                            }
+                            const half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                            *(half4*)(D + (long long)m * p.ldd + n) = h;
                         }
-                        const half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-                        *(half4*)(D + (long long)m * p.ldd + n) = h;
                     }
                 }
             }

@@ -23,7 +23,19 @@ struct GemmDev {
     int splitk; float* ws;   // splitk > 1: raw fp32 partial tiles go to ws[ks][M][Npad], reduced by splitk_reduce_kernel
 };
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU, 0.5*x*(1+erf(x/sqrt2)), with erf from Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the
+// fp16 rounding of the result): one rcp + one exp + five fma instead of libm's branchy erff in the GEMM epilogue.
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = 1.0f - poly * t * __expf(-z * z);     // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
 
 // ------------------------------------------------------------------------------------------ epilogue (shared)
 // Handles 4 consecutive columns n..n+3 of row m held in v[0..3].
