@@ -150,7 +150,7 @@ void launch_approx_decode(const LaunchCtx& ctx, const float* lat, float* img, in
 struct RepackDev {
     const void* src; int src_is_f16;
     int O, I, KH, KW, in_out;
-    half_t* dst; int dst_row0, Ipad, i0, Kdst, geglu_half;
+    half_t* dst; int dst_row0, Ipad, i0, Kdst, geglu_half, geglu_pair;
 };
 __global__ void repack_kernel(RepackDev a)
 {
@@ -168,14 +168,14 @@ __global__ void repack_kernel(RepackDev a)
         int row = o;
         if (a.geglu_half > 0) {
             int j = o < a.geglu_half ? o : o - a.geglu_half;
-            row = 32 * (j >> 4) + (j & 15) + (o < a.geglu_half ? 0 : 16);
+            row = a.geglu_pair ? 2 * j + (o < a.geglu_half ? 0 : 1) : 32 * (j >> 4) + (j & 15) + (o < a.geglu_half ? 0 : 16);
         }
         a.dst[(long long)(a.dst_row0 + row) * a.Kdst + (long long)tap * a.Ipad + a.i0 + i] = (half_t)v;
     }
 }
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& r)
 {
-    RepackDev a{r.src, r.src_is_f16, r.O, r.I, r.KH, r.KW, r.in_out, r.dst, r.dst_row0, r.Ipad, r.i0, r.Kdst, r.geglu_half};
+    RepackDev a{r.src, r.src_is_f16, r.O, r.I, r.KH, r.KW, r.in_out, r.dst, r.dst_row0, r.Ipad, r.i0, r.Kdst, r.geglu_half, r.geglu_pair};
     long long total = (long long)a.O * a.I * a.KH * a.KW;
     hipLaunchKernelGGL(repack_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 8192)), dim3(256), 0, ctx.stream, a);
     HIP_CHECK(hipGetLastError());

@@ -205,7 +205,8 @@ __global__ void gemm_naive_kernel(GemmDev p)
     const half_t* A0 = p.A0 + z * p.sA;
     const half_t* A1 = p.A1 ? p.A1 + z * p.sA : nullptr;
     const half_t* Wp = p.W + z * p.sW;
-    const int Nout = p.epi == EPI_GEGLU ? (p.N >> 1) : p.N;
+    const bool gg = p.epi == EPI_GEGLU || p.epi == EPI_GEGLU_PAIR;
+    const int Nout = gg ? (p.N >> 1) : p.N;
     const int groups = (Nout + 3) >> 2;
     long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (long long)p.M * groups) return;
@@ -223,6 +224,7 @@ __global__ void gemm_naive_kernel(GemmDev p)
         // weight rows: GEGLU weights are interleaved in 16-blocks: out col j -> value row 32*(j/16)+j%16, gate row +16
         int wrow = n, grow = 0;
         if (p.epi == EPI_GEGLU) { wrow = 32 * (n >> 4) + (n & 15); grow = wrow + 16; }
+        if (p.epi == EPI_GEGLU_PAIR) { wrow = 2 * n; grow = 2 * n + 1; }
         float s = 0.f, sg = 0.f;
         for (int tap = 0; tap < p.taps; ++tap) {
             long long pix; bool ok = true;
@@ -238,14 +240,14 @@ __global__ void gemm_naive_kernel(GemmDev p)
             for (int c = 0; c < p.C0; ++c) {
                 float x = (float)a0[c];
                 s += x * (float)wr[c];
-                if (p.epi == EPI_GEGLU) sg += x * (float)wg[c];
+                if (gg) sg += x * (float)wg[c];
             }
             if (p.C1) {
                 const half_t* a1 = A1 + pix * p.lda1;
                 for (int c = 0; c < p.C1; ++c) {
                     float x = (float)a1[c];
                     s += x * (float)wr[p.C0 + c];
-                    if (p.epi == EPI_GEGLU) sg += x * (float)wg[p.C0 + c];
+                    if (gg) sg += x * (float)wg[p.C0 + c];
                 }
             }
         }
@@ -283,6 +285,7 @@ bool gemm_mfma_supported(const GemmArgs& a)
     if (a.lda0 % 8 || (a.C1 && a.lda1 % 8)) return false;          // 16-B aligned source chunks
     if (a.Npad % 128 && a.Npad % 160) return false;
     if (a.epi == EPI_GEGLU && (a.N % 64 || a.Npad % 128)) return false;
+    if (a.epi == EPI_GEGLU_PAIR) return false;   // pairwise layout: gemm_big.hip only
     if ((a.epi == EPI_STD || a.epi == EPI_GEGLU) && (a.ldd % 4 || (a.R && a.ldr % 4))) return false;
     if ((reinterpret_cast<uintptr_t>(a.A0) | reinterpret_cast<uintptr_t>(a.W)) & 15) return false;
     if ((a.sA | a.sW) % 8 || (a.sD | a.sR) % 4) return false;
@@ -324,7 +327,7 @@ static const char* prof_name(const char* base, const GemmArgs& a, const char* ke
     static const bool shapes = getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"));
     if (!shapes) return base;
     static thread_local char buf[48];
-    snprintf(buf, sizeof(buf), "%s%s M%d N%d K%d%s%s", a.taps == 9 ? "c3" : (a.epi == EPI_GEGLU ? "gg" : "g1"), kern, a.M, a.N, a.K,
+    snprintf(buf, sizeof(buf), "%s%s M%d N%d K%d%s%s", a.taps == 9 ? "c3" : ((a.epi == EPI_GEGLU || a.epi == EPI_GEGLU_PAIR) ? "gg" : "g1"), kern, a.M, a.N, a.K,
              a.R ? " R" : "", a.batch > 1 ? " b" : "");
     return buf;
 }
@@ -350,8 +353,8 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;   // slab traffic must stay small next to the GEMM
         }
-        if (big_env == 2 || ctx.force_big || tiles * sk >= 192) {
-            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma" : "gemm_mfma", a, "B"), flops, bytes);
+        if (big_env == 2 || ctx.force_big || tiles * sk >= 192 || a.epi == EPI_GEGLU_PAIR) {
+            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU_PAIR ? "gemm_geglu_mfma" : "gemm_mfma"), a, "B"), flops, bytes);
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
             launch_gemm_big(ctx, p, a.batch, a.taps == 9);
             if (sk > 1) {
@@ -382,7 +385,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         }
     } else {
         ProfScope ps(ctx, a.taps == 9 ? "conv3x3_plain" : "gemm_plain", flops, bytes);
-        const int Nout = a.epi == EPI_GEGLU ? a.N / 2 : a.N;
+        const int Nout = (a.epi == EPI_GEGLU || a.epi == EPI_GEGLU_PAIR) ? a.N / 2 : a.N;
         long long total = (long long)a.M * ((Nout + 3) / 4);
         dim3 grid((unsigned)cdiv64(total, 256), 1, a.batch);
         hipLaunchKernelGGL(gemm_naive_kernel, grid, dim3(256), 0, ctx.stream, p);

@@ -233,6 +233,40 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         }
         return;
     }
+    if (p.epi == EPI_GEGLU_PAIR) {
+        // weight rows interleaved pairwise: a lane's 4 consecutive n are (value_j, gate_j, value_j+1, gate_j+1), j = n/2
+        const int half_n = p.N >> 1;
+        float bvv[5][2], bvg[5][2];
+#pragma unroll
+        for (int nt = 0; nt < 5; ++nt) {
+            const int j = (n0 + wc * 80 + nt * 16 + 4 * fg) >> 1;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const bool ok = p.bias && j + r < half_n;
+                bvv[nt][r] = ok ? p.bias[j + r] : 0.f;
+                bvg[nt][r] = ok ? p.bias[half_n + j + r] : 0.f;
+            }
+        }
+        half_t* D = p.D + zD;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            const int m = m0 + wr * 128 + mt * 16 + fr;
+            if (m < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < 5; ++nt) {
+                    const int j = (n0 + wc * 80 + nt * 16 + 4 * fg) >> 1;
+                    if (j + 1 < half_n) {
+                        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+                        const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * gelu_erf(acc[nt][mt][1] + bvg[nt][0])),
+                                           (half_t)((acc[nt][mt][2] + bvv[nt][1]) * gelu_erf(acc[nt][mt][3] + bvg[nt][1]))};
+                        *(half2_t*)(D + (long long)m * p.ldd + j) = h;
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        return;
+    }
     {   // EPI_STD with N % 4 == 0 (checked on the host), one row group at a time so the 160 accumulators stay in registers
         float bv[5][4];
 #pragma unroll
@@ -288,8 +322,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 // ------------------------------------------------------------------------------------------ host side
 bool gemm_big_supported(const GemmArgs& a)
 {
-    if (!gemm_mfma_supported(a)) return false;
-    if (a.Npad % BN || a.epi != EPI_STD || (a.N & 3)) return false;   // other epilogues stay on gemm.hip's kernel
+    GemmArgs c = a;
+    if (c.epi == EPI_GEGLU_PAIR) { c.epi = EPI_TRANS; }   // shared operand/alignment rules without gemm.hip's own epilogue constraints
+    if (!gemm_mfma_supported(c)) return false;
+    if (a.Npad % BN || (a.epi != EPI_STD && a.epi != EPI_GEGLU_PAIR) || (a.N & 3)) return false;   // other epilogues stay on gemm.hip's kernel
+    if (a.epi == EPI_GEGLU_PAIR && (a.ldd & 1)) return false;
     // 32-bit byte offsets inside a 2 GiB descriptor window; 24-bit pixel index / row pitch for the mad
     const long long rowsA = a.taps == 9 ? (long long)(a.M / (a.Ho * a.Wo)) * (a.ups ? (a.Hi / 2) * (a.Wi / 2) : a.Hi * a.Wi) : a.M;
     if (rowsA >= (1 << 24) || a.lda0 * 2 >= (1 << 24) || a.lda1 * 2 >= (1 << 24)) return false;

@@ -66,7 +66,7 @@ __device__ __forceinline__ void epilogue4(const GemmDev& p, int m, int n, floatx
                 p.D[zD + (long long)m * p.ldd + n + r] = (half_t)x;
             }
         }
-    } else if (p.epi == EPI_GEGLU) {
+    } else if (p.epi == EPI_GEGLU || p.epi == EPI_GEGLU_PAIR) {
         // v = value columns, vg = gate columns for output columns j..j+3 (j passed in n)
         int half_n = p.N >> 1;
         if (n >= half_n) return;

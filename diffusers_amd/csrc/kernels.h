@@ -33,7 +33,8 @@ enum GemmEpilogue {
     EPI_GEGLU = 1,     // weights row-interleaved in 16-blocks (value,gate); D[m][j] = (a+ba) * gelu_erf(g+bg), ldd >= N/2
     EPI_NCHW_F32 = 2,  // Df[(nb*N + n)*HoWo + pix] = acc + bias          (UNet / VAE graph output)
     EPI_IMAGE = 3,     // Df[m*N + n] = clamp((acc + bias)/2 + 0.5, 0, 1)   (decode_latents post-processing)
-    EPI_TRANS = 4      // D[n*ldd + m] = half(alpha*acc + bias[n])
+    EPI_TRANS = 4,     // D[n*ldd + m] = half(alpha*acc + bias[n])
+    EPI_GEGLU_PAIR = 5 // as EPI_GEGLU with weight rows interleaved pairwise: row 2j = value_j, row 2j+1 = gate_j (gemm_big.hip)
 };
 
 struct GemmArgs {
@@ -123,6 +124,7 @@ struct RepackArgs {
     int i0 = 0;                                // channel offset inside the tap where this source starts
     int Kdst = 0;                              // dst row length
     int geglu_half = 0;                        // >0: row o -> interleaved row (16-block value/gate), value = geglu_half
+    int geglu_pair = 0;                        // with geglu_half: pairwise interleave instead (value_j -> 2j, gate_j -> 2j+1)
 };
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& a);
 

@@ -69,6 +69,8 @@ DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std
     const int Ipad = cin_pad > 0 ? cin_pad : I;
     SDE_REQUIRE(Ipad >= I, SDE_ERR_MODEL, "cin_pad smaller than Cin for " + names[0]);
     L.taps = kh * kw; L.Cin = Ipad; L.K = L.taps * Ipad; L.N = N; L.Npad = gemm_npad(N); L.geglu = geglu;
+    // wide GEGLU projections run on the 256x320 kernel, which wants value/gate of a column in one lane: pairwise interleave
+    L.geglu_pair = geglu && N % 320 == 0 && L.K % 64 == 0 && L.taps == 1;
     const size_t wbytes = (size_t)L.Npad * L.K * sizeof(half_t);
     L.W = (half_t*)dmalloc(wbytes);
     HIP_CHECK(hipMemsetAsync(L.W, 0, wbytes, ctx.stream));
@@ -87,7 +89,7 @@ DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std
         r.O = (int)(b.t->dims.size() == 4 ? b.t->dims[0] : b.out_dim());
         r.I = I; r.KH = kh; r.KW = kw; r.in_out = b.in_out ? 1 : 0;
         r.dst = L.W; r.dst_row0 = row0; r.Ipad = Ipad; r.i0 = 0; r.Kdst = L.K;
-        r.geglu_half = geglu ? r.O / 2 : 0;
+        r.geglu_half = geglu ? r.O / 2 : 0; r.geglu_pair = L.geglu_pair ? 1 : 0;
         if (geglu) SDE_REQUIRE(names.size() == 1 && (r.O / 2) % 16 == 0, SDE_ERR_MODEL, "GEGLU projection width must be a multiple of 32");
         launch_repack(ctx, r);
         // the host->device copy of pageable memory may still be reading `staging` asynchronously only on the device side;
@@ -123,7 +125,7 @@ void linear(Exec& ex, const DevLinear& L, const half_t* A, int lda, int M, half_
     g.A0 = A; g.lda0 = lda; g.C0 = A1 ? C0 : L.K; g.A1 = A1; g.C1 = A1 ? C1 : 0; g.lda1 = lda1;
     g.M = M; g.N = L.N; g.K = L.K; g.taps = 1;
     g.W = L.W; g.Npad = L.Npad; g.bias = L.bias; g.R = R; g.ldr = ldr; g.D = D; g.ldd = ldd;
-    g.epi = L.geglu ? EPI_GEGLU : EPI_STD;
+    g.epi = L.geglu ? (L.geglu_pair ? EPI_GEGLU_PAIR : EPI_GEGLU) : EPI_STD;
     SDE_REQUIRE(L.taps == 1 && g.C0 + g.C1 == L.K, SDE_ERR_MODEL, "linear: operand width mismatch");
     run_gemm(ex, g);
 }

@@ -115,7 +115,9 @@ def run_attn(engine, naive, q, k, v, heads):
 ATTN_CASES = [
     # NB, heads, Sq, Skv, d
     (2, 8, 256, 256, 40),     # SD1.5 level-0 head dim
-    (1, 8, 1024, 1024, 40),
+    (1, 8, 1024, 1024, 40),   # 64-row-per-wave, double-buffered variant
+    (1, 2, 1100, 1100, 40),   # same, ragged query block and masked last key tile
+    (1, 3, 1030, 320, 64),    # same, d = 64 (no spare V column: VALU row sums), odd tile count
     (2, 8, 256, 77, 40),      # cross attention, ragged key count
     (1, 8, 64, 64, 160),      # deepest level
     (2, 8, 200, 152, 80),     # ragged query tile + 2-chunk prompt

@@ -43,7 +43,7 @@ def main():
         for s in st:
             us = s["total_ms"] / s["launches"] * 1e3
             print(f"conv k{k} s{stride} u{ups} {H:3d}^2 {Cin:5d}->{Cout:5d}  M={NB*Ho*Ho:6d}  {us:9.1f} us  {s['flops']/s['launches']/us/1e6:7.1f} TFLOP/s", flush=True)
-    for (heads, Sq, Skv, dd) in ([] if only else ATTN):
+    for (heads, Sq, Skv, dd) in (ATTN if only in ("", "attn") else []):
         q = rng.standard_normal((NB, Sq, heads * dd), dtype=np.float32)
         kk = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
         v = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
