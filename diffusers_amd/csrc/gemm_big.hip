@@ -30,16 +30,24 @@ constexpr int RSRC_FLAGS = 0x00020000;
 
 }  // namespace
 
-template <bool CONV>
+// VAR: 0 in the product.  Diagnostic builds (-DSDE_DIAG, wrong results, timing only): bit0 = no loads in the main loop,
+// bit1 = no fragment reads, bit2 = no barriers.
+template <bool CONV, bool UPS, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // loads issued per section for the next K-tile; sections are L0 M0 L1 M1 L2 M2 L3 M3 (L = load, M = MFMA section).
     // Waves 0-3 may not touch the other buffer before M0 (waves 4-7 are still reading it during L0).
-    constexpr int kSched[2][8] = {
-        {0, 2, 2, 1, 2, 2, 0, 0},   // waves 0-3
-        {3, 1, 2, 1, 2, 0, 0, 0},   // waves 4-7
+    // Measured (tools/microbench.py, MI355X): issuing only in load sections beats any placement among the MFMAs by 5-9 %.
+    // Measured (tools/microbench.py, MI355X): placements differ by +-3 %; the cost is the load path's throughput, not the slot.
+    constexpr int kScheds[4][2][8] = {
+        {{0, 0, 5, 0, 4, 0, 0, 0}, {4, 0, 5, 0, 0, 0, 0, 0}},   // product schedule: load sections only, early in the tile
+        {{0, 2, 2, 1, 2, 2, 0, 0}, {3, 1, 2, 1, 2, 0, 0, 0}},   // diagnostic alternatives (VAR >> 4, -DSDE_DIAG builds)
+        {{0, 3, 0, 3, 0, 3, 0, 0}, {0, 3, 0, 3, 0, 3, 0, 0}},
+        {{0, 1, 3, 1, 2, 0, 2, 0}, {3, 1, 3, 0, 2, 0, 0, 0}},
     };
+    static_assert(kScheds[VAR >> 4][0][0] == 0 && kScheds[VAR >> 4][1][6] == 0 && kScheds[VAR >> 4][0][7] == 0 && kScheds[VAR >> 4][1][7] == 0, "illegal issue slot");
+#define kSched kScheds[VAR >> 4]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,12 +79,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     //      wave w stages rows 8w..8w+7 of the part, lane -> (row = lane>>3, 16-B chunk = (lane&7) ^ row)
     const int srow = lane >> 3;
     const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
-    int a_pix[NPA];        // source pixel index of the window centre (conv) / row index (linear)
-    unsigned a_mask[NPA];  // bit t: tap t in bounds (and row < M); bits 9,10: oy,ox parity (fused 2x upsample)
+    unsigned a_off0[NPA], a_off1[NPA];   // byte offset of the window-centre pixel (conv) / row (linear) + swizzled chunk, per source
+    unsigned a_mask[NPA];                // bit t: tap t in bounds (and row < M); bits 9,10: oy,ox parity (fused 2x upsample)
 #pragma unroll
     for (int j = 0; j < NPA; ++j) {
         const int m = m0 + j * 64 + wid * 8 + srow;
         const bool ok = m < p.M;
+        int pix = m;
         if (CONV) {
             const int hw = p.Ho * p.Wo;
             const int nb = m / hw, rem = m - nb * hw;
@@ -90,47 +99,58 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             }
             mask |= (unsigned)(cy & 1) << 9 | (unsigned)(cx & 1) << 10;
             a_mask[j] = mask;
-            a_pix[j] = nb * p.Hs * p.Ws + (cy >> p.ups) * p.Ws + (cx >> p.ups);
+            pix = nb * p.Hs * p.Ws + (cy >> (UPS ? 1 : 0)) * p.Ws + (cx >> (UPS ? 1 : 0));
         } else {
             a_mask[j] = ok ? 1u : 0u;
-            a_pix[j] = m;
         }
+        a_off0[j] = (unsigned)pix * (unsigned)(p.lda0 * 2) + lchunk16;
+        a_off1[j] = (unsigned)pix * (unsigned)(p.lda1 * 2) + lchunk16;
     }
     const unsigned w_off = (unsigned)((n0 + wid * 8 + srow) * p.K) * 2u + lchunk16;
     const int Ctot = p.C0 + p.C1;
+    const int w_part = 128 * p.K;   // byte stride between 64-row W parts
 
-    // staging state of the K-tile currently being issued (wave-uniform)
+    // staging state of the K-tile currently being issued (wave-uniform scalars, recomputed once per K-tile)
     int st_k0 = kt0 << 6, st_tap = 0, st_c = st_k0;
     if (CONV) { st_tap = st_k0 / Ctot; st_c = st_k0 - st_tap * Ctot; }
+    bool st_second = false;      // the K-tile's channels come from the second source of a concat
+    unsigned st_bit = 1u;        // 1 << tap
+    int st_add = 0;              // byte offset of (tap, channel) relative to the window centre (not UPS: includes the tap shift)
+    int st_ld2 = 0, st_ey0 = 0, st_ey1 = 0, st_ex0 = 0, st_ex1 = 0;   // UPS only: per-parity tap shifts
+    auto stage_scalars = [&]() {
+        st_second = st_c >= p.C0;
+        const int ld2 = (st_second ? p.lda1 : p.lda0) * 2;
+        st_add = (st_second ? st_c - p.C0 : st_c) * 2;
+        if (CONV) {
+            const int dy = st_tap / 3, dx = st_tap - dy * 3;
+            st_bit = 1u << st_tap;
+            if (UPS) { st_ld2 = ld2; st_ey0 = -(dy == 0); st_ey1 = (dy == 2); st_ex0 = -(dx == 0); st_ex1 = (dx == 2); }
+            else st_add += ((dy - 1) * p.Ws + (dx - 1)) * ld2;
+        }
+    };
+    stage_scalars();
     auto stage_advance = [&]() {
         st_k0 += 64; st_c += 64;
         if (CONV && st_c >= Ctot) { st_c = 0; ++st_tap; }
+        stage_scalars();
     };
     // issue staging part j of the current staging K-tile into buffer `buf`
     auto issue = [&](int j, int buf) {
         char* dst = smem + buf * STAGE + (j < NPA ? j * 8192 : A_BYTES + (j - NPA) * 8192) + wid * 1024;
-        if (j < NPA) {
-            const bool second = st_c >= p.C0;
-            const int ld2 = (second ? p.lda1 : p.lda0) * 2;
-            const unsigned cc2 = (unsigned)(second ? st_c - p.C0 : st_c) * 2u + lchunk16;
-            int delta = 0;
-            if (CONV) {
-                const int dy = st_tap / 3, dx = st_tap - dy * 3;
-                if (p.ups) {
-                    const int ey = (a_mask[j] >> 9) & 1 ? (dy == 2) : -(dy == 0);
-                    const int ex = (a_mask[j] >> 10) & 1 ? (dx == 2) : -(dx == 0);
-                    delta = ey * p.Ws + ex;
-                } else {
-                    delta = (dy - 1) * p.Ws + (dx - 1);
-                }
+        if (VAR & 8) {   // diagnostic: same instruction stream to the memory system, no address arithmetic
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, 0, 0, 0);
+        } else if (j < NPA) {
+            unsigned voff = (st_second ? a_off1[j] : a_off0[j]) + (unsigned)st_add;
+            if (CONV && UPS) {
+                const int ey = (a_mask[j] >> 9) & 1 ? st_ey1 : st_ey0;
+                const int ex = (a_mask[j] >> 10) & 1 ? st_ex1 : st_ex0;
+                voff += (unsigned)(__mul24(__mul24(ey, p.Ws) + ex, st_ld2));
             }
-            const bool valid = (a_mask[j] >> st_tap) & 1;
-            const unsigned voff = valid ? (unsigned)__umul24((unsigned)(a_pix[j] + delta), (unsigned)ld2) + cc2 : OOB;
-            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, LDS_PTR(dst), 16, voff, 0, 0, 0);
-            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
+            voff = (a_mask[j] & st_bit) ? voff : OOB;
+            if (st_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, LDS_PTR(dst), 16, voff, 0, 0, 0);
+            else           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
         } else {
-            const int soff = (j - NPA) * 128 * p.K + st_k0 * 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, (j - NPA) * w_part + st_k0 * 2, 0, 0);
         }
     };
 
@@ -145,6 +165,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
     half8 bf[5], af[4];
+    if (VAR & 2) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) bf[i] = *(const half8*)(smem + lane * 16 + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(smem + lane * 16 + 8192 + i * 1024);
+    }
 
     // ---- prologue: K-tile 0 into buffer 0
 #pragma unroll
@@ -155,11 +181,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
 
 #define LOAD_B(ofs)                                                                                   \
-    _Pragma("unroll") for (int nt = 0; nt < 5; ++nt) bf[nt] = *(const half8*)(cur + (ofs) + nt * 2048);
+    if (!(VAR & 2)) _Pragma("unroll") for (int nt = 0; nt < 5; ++nt) bf[nt] = *(const half8*)(cur + (ofs) + nt * 2048);
 #define LOAD_A(ofs, mh)                                                                               \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) af[mt] = *(const half8*)(cur + (ofs) + ((mh) * 4 + mt) * 2048);
+    if (!(VAR & 2)) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) af[mt] = *(const half8*)(cur + (ofs) + ((mh) * 4 + mt) * 2048);
 #define ISSUE_N(sec)                                                                                  \
-    if (more) {                                                                                       \
+    if (more && !(VAR & 1)) {                                                                         \
         _Pragma("unroll") for (int i = 0; i < kSched[0][sec]; ++i) if (wr == 0) issue(jn0 + i, nb_);   \
         _Pragma("unroll") for (int i = 0; i < kSched[1][sec]; ++i) if (wr == 1) issue(jn1 + i, nb_);   \
     }                                                                                                 \
@@ -172,6 +198,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     __builtin_amdgcn_s_setprio(0);
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
+#define BAR() do { if (!(VAR & 4)) __builtin_amdgcn_s_barrier(); } while (0)
     for (int kt = 0; kt < nk; ++kt) {
         const char* cur = smem + (kt & 1) * STAGE;
         const int nb_ = (kt & 1) ^ 1;
@@ -180,36 +207,39 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         // phase 0: (m-half 0, k-half 0)
         LOAD_B(b_rd0) LOAD_A(a_rd0, 0)
         ISSUE_N(0)
-        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        FENCE(); BAR(); FENCE();
         ISSUE_N(1)
         MFMA_BLOCK(0)
-        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        FENCE(); BAR(); FENCE();
         // phase 1: (m-half 1, k-half 0)
         LOAD_A(a_rd0, 1)
         ISSUE_N(2)
-        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        FENCE(); BAR(); FENCE();
         ISSUE_N(3)
         MFMA_BLOCK(1)
-        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        FENCE(); BAR(); FENCE();
         // phase 2: (m-half 1, k-half 1)
         LOAD_B(b_rd1) LOAD_A(a_rd1, 1)
         ISSUE_N(4)
-        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        FENCE(); BAR(); FENCE();
         ISSUE_N(5)
         MFMA_BLOCK(1)
-        FENCE(); __builtin_amdgcn_s_barrier(); FENCE();
+        FENCE(); BAR(); FENCE();
         // phase 3: (m-half 0, k-half 1)
         LOAD_A(a_rd1, 0)
+        ISSUE_N(6)   // waves 0-3 only (waves 4-7 wait for their loads right below)
         FENCE();
         if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves 4-7: last issue was in L2, two sections ago
-        __builtin_amdgcn_s_barrier(); FENCE();
+        BAR(); FENCE();
         MFMA_BLOCK(0)
         FENCE();
-        if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves 0-3: last issue was in M2, two sections ago
-        __builtin_amdgcn_s_barrier(); FENCE();
+        if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves 0-3: last issue at the latest in L3, one MFMA section ago
+        BAR(); FENCE();
         if (more) stage_advance();
     }
+#undef BAR
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7
+#undef kSched
 #undef LOAD_B
 #undef LOAD_A
 #undef ISSUE_N
@@ -329,7 +359,7 @@ bool gemm_big_supported(const GemmArgs& a)
     if (a.epi == EPI_GEGLU_PAIR && (a.ldd & 1)) return false;
     // 32-bit byte offsets inside a 2 GiB descriptor window; 24-bit pixel index / row pitch for the mad
     const long long rowsA = a.taps == 9 ? (long long)(a.M / (a.Ho * a.Wo)) * (a.ups ? (a.Hi / 2) * (a.Wi / 2) : a.Hi * a.Wi) : a.M;
-    if (rowsA >= (1 << 24) || a.lda0 * 2 >= (1 << 24) || a.lda1 * 2 >= (1 << 24)) return false;
+    if (rowsA >= (1 << 24) || a.lda0 * 2 >= (1 << 23) || a.lda1 * 2 >= (1 << 23) || a.Wi >= (1 << 16)) return false;
     if (rowsA * std::max(a.lda0, a.lda1) * 2 >= 0x7ff00000LL) return false;
     if ((long long)a.Npad * a.K * 2 >= 0x7ff00000LL) return false;
     return true;
@@ -339,13 +369,24 @@ void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         attr_set = true;
     }
     p.nbm = cdiv(p.M, BM);
     p.nbn = p.Npad / BN;
     dim3 grid(p.nbm * p.nbn, p.splitk, batch);
-    if (conv) hipLaunchKernelGGL(gemm_big_kernel<true>, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
-    else      hipLaunchKernelGGL(gemm_big_kernel<false>, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+#ifdef SDE_DIAG
+    static const int var = getenv("SDE_BIGVAR") ? atoi(getenv("SDE_BIGVAR")) : 0;
+    if (conv && !p.ups && var) {
+#define DIAG(V) case V: { static bool s = false; if (!s) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES)); s = true; } \
+        hipLaunchKernelGGL((gemm_big_kernel<true, false, V>), grid, dim3(512), SMEM_BYTES, ctx.stream, p); return; }
+        switch (var) { DIAG(1) DIAG(2) DIAG(3) DIAG(8) DIAG(16) DIAG(32) DIAG(48) default: break; }
+#undef DIAG
+    }
+#endif
+    if (conv && p.ups) hipLaunchKernelGGL((gemm_big_kernel<true, true>), grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+    else if (conv)     hipLaunchKernelGGL((gemm_big_kernel<true, false>), grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+    else               hipLaunchKernelGGL((gemm_big_kernel<false, false>), grid, dim3(512), SMEM_BYTES, ctx.stream, p);
 }
