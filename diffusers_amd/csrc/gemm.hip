@@ -354,7 +354,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;   // slab traffic must stay small next to the GEMM
         }
         if (big_env == 2 || ctx.force_big || tiles * sk >= 192 || a.epi == EPI_GEGLU_PAIR) {
-            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU_PAIR ? "gemm_geglu_mfma" : "gemm_mfma"), a, "B"), flops, bytes);
+            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma_256x320" : (a.epi == EPI_GEGLU_PAIR ? "gemm_geglu_mfma_256x320" : "gemm_mfma_256x320"), a, "B"), flops, bytes);
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
             launch_gemm_big(ctx, p, a.batch, a.taps == 9);
             if (sk > 1) {

@@ -14,7 +14,7 @@
 //   * Each K-tile is 4 phases (m-half x k-half) of {ds_read fragments, issue loads | barrier | 20 MFMA | barrier}.
 //     Waves 4-7 run one barrier behind waves 0-3, so on every SIMD one wave is in its MFMA section while its
 //     partner is in its load section.  Loads for K-tile t+1 are spread over the sections of tile t and retired with
-//     one s_waitcnt vmcnt(0) per tile placed two sections after the last issue (never right behind an issue).
+//     one s_waitcnt vmcnt(0) per tile placed at least one full section after the last issue (never right behind an issue).
 //   * XCD-aware bijective block remap, optional split-K (partial fp32 slabs reduced by gemm.hip's reduce kernel).
 #include "gemm_common.h"
 
@@ -38,7 +38,6 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // loads issued per section for the next K-tile; sections are L0 M0 L1 M1 L2 M2 L3 M3 (L = load, M = MFMA section).
     // Waves 0-3 may not touch the other buffer before M0 (waves 4-7 are still reading it during L0).
-    // Measured (tools/microbench.py, MI355X): issuing only in load sections beats any placement among the MFMAs by 5-9 %.
     // Measured (tools/microbench.py, MI355X): placements differ by +-3 %; the cost is the load path's throughput, not the slot.
     constexpr int kScheds[4][2][8] = {
         {{0, 0, 5, 0, 4, 0, 0, 0}, {4, 0, 5, 0, 0, 0, 0, 0}},   // product schedule: load sections only, early in the tile
