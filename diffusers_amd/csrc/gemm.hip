@@ -259,6 +259,7 @@ __global__ void gemm_naive_kernel(GemmDev p)
 // ------------------------------------------------------------------------------------------ host side
 struct GemmDev;
 bool gemm_big_supported(const GemmArgs& a);                                        // gemm_big.hip
+int gemm_big_bn(const GemmArgs& a);
 void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 
 int gemm_npad(int N) { return (N % 160 == 0 || N % 128 == 0) ? N : round_up(N, 128); }
@@ -346,7 +347,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     static const int big_env = getenv("SDE_BIG") ? atoi(getenv("SDE_BIG")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
     if (!ctx.force_naive && big_env && gemm_big_supported(a)) {
         // 8-wave 256x320 tiles, one block per CU: worth it once the grid (with split-K on long K) covers most of the chip
-        const int tiles = cdiv(a.M, 256) * (a.Npad / 320) * a.batch, nk = a.K >> 6;
+        const int tiles = cdiv(a.M, 256) * (a.Npad / gemm_big_bn(a)) * a.batch, nk = a.K >> 6;
         int sk = 1;
         if (a.batch == 1 && ctx.splitk_ws && tiles < 192 && nk >= 64) {
             sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 32), 2);   // deeper splits: the 4-wave kernel's slabs are cheaper

@@ -21,10 +21,10 @@
 #include <algorithm>
 
 namespace {
-constexpr int BM = 256, BN = 320;
-constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;   // 73,728 B per K-tile
-constexpr int SMEM_BYTES = 2 * STAGE;                                               // 147,456 B
-constexpr int NPA = BM / 64, NPB = BN / 64, NPART = NPA + NPB;                      // 64-row staging parts: 4 + 5
+constexpr int BM = 256;
+constexpr int A_BYTES = BM * 128;
+constexpr int NPA = BM / 64;                                                        // 64-row staging parts of the A tile
+constexpr int smem_bytes(int nt) { return 2 * (BM + nt * 64) * 128; }               // NT = 5: 147,456 B ; NT = 4: 131,072 B
 constexpr unsigned OOB = 0x80000000u;                                               // >= num_records -> reads as zero
 constexpr int RSRC_FLAGS = 0x00020000;
 
@@ -32,18 +32,22 @@ constexpr int RSRC_FLAGS = 0x00020000;
 
 // VAR: 0 in the product.  Diagnostic builds (-DSDE_DIAG, wrong results, timing only): bit0 = no loads in the main loop,
 // bit1 = no fragment reads, bit2 = no barriers.
-template <bool CONV, bool UPS, int VAR = 0>
+// NT = 16-column tiles per wave: 5 -> 256x320 block tile (UNet widths 320/640/1280), 4 -> 256x256 (VAE widths 256/512).
+template <bool CONV, bool UPS, int NT, int VAR = 0>
 __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BN = NT * 64, WN = NT * 16;                       // block / wave tile width
+    constexpr int STAGE = A_BYTES + BN * 128;                       // bytes per K-tile buffer
+    constexpr int NPART = NPA + NT;                                 // staging parts per K-tile (A: 4, W: NT)
     // loads issued per section for the next K-tile; sections are L0 M0 L1 M1 L2 M2 L3 M3 (L = load, M = MFMA section).
     // Waves 0-3 may not touch the other buffer before M0 (waves 4-7 are still reading it during L0).
     // Measured (tools/microbench.py, MI355X): placements differ by +-3 %; the cost is the load path's throughput, not the slot.
     constexpr int kScheds[4][2][8] = {
-        {{0, 0, 5, 0, 4, 0, 0, 0}, {4, 0, 5, 0, 0, 0, 0, 0}},   // product schedule: load sections only, early in the tile
-        {{0, 2, 2, 1, 2, 2, 0, 0}, {3, 1, 2, 1, 2, 0, 0, 0}},   // diagnostic alternatives (VAR >> 4, -DSDE_DIAG builds)
-        {{0, 3, 0, 3, 0, 3, 0, 0}, {0, 3, 0, 3, 0, 3, 0, 0}},
-        {{0, 1, 3, 1, 2, 0, 2, 0}, {3, 1, 3, 0, 2, 0, 0, 0}},
+        {{0, 0, NT, 0, 4, 0, 0, 0}, {4, 0, NT, 0, 0, 0, 0, 0}},   // product schedule: load sections only, early in the tile
+        {{0, 2, 2, 1, 2, NT - 3, 0, 0}, {3, 1, 2, 1, NT - 3, 0, 0, 0}},   // diagnostic alternatives (VAR >> 4, -DSDE_DIAG builds)
+        {{0, 3, 0, 3, 0, NT - 2, 0, 0}, {0, 3, 0, 3, 0, NT - 2, 0, 0}},
+        {{0, 1, 3, 1, 2, 0, NT - 3, 0}, {3, 1, 3, 0, NT - 3, 0, 0, 0}},
     };
     static_assert(kScheds[VAR >> 4][0][0] == 0 && kScheds[VAR >> 4][1][6] == 0 && kScheds[VAR >> 4][0][7] == 0 && kScheds[VAR >> 4][1][7] == 0, "illegal issue slot");
 #define kSched kScheds[VAR >> 4]
@@ -153,20 +157,20 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         }
     };
 
-    // ---- fragment read addresses (swizzled): A rows wr*128 + mt*16 + fr, W rows wc*80 + nt*16 + fr
+    // ---- fragment read addresses (swizzled): A rows wr*128 + mt*16 + fr, W rows wc*WN + nt*16 + fr
     const int swz0 = ((fg) ^ (fr & 7)) << 4, swz1 = ((4 + fg) ^ (fr & 7)) << 4;
     const int a_rd0 = (wr * 128 + fr) * 128 + swz0, a_rd1 = (wr * 128 + fr) * 128 + swz1;
-    const int b_rd0 = A_BYTES + (wc * 80 + fr) * 128 + swz0, b_rd1 = A_BYTES + (wc * 80 + fr) * 128 + swz1;
+    const int b_rd0 = A_BYTES + (wc * WN + fr) * 128 + swz0, b_rd1 = A_BYTES + (wc * WN + fr) * 128 + swz1;
 
-    floatx4 acc[5][8];
+    floatx4 acc[NT][8];
 #pragma unroll
-    for (int a = 0; a < 5; ++a)
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
-    half8 bf[5], af[4];
+    half8 bf[NT], af[4];
     if (VAR & 2) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) bf[i] = *(const half8*)(smem + lane * 16 + i * 1024);
+        for (int i = 0; i < NT; ++i) bf[i] = *(const half8*)(smem + lane * 16 + i * 1024);
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const half8*)(smem + lane * 16 + 8192 + i * 1024);
     }
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     if (wr == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
 
 #define LOAD_B(ofs)                                                                                   \
-    if (!(VAR & 2)) _Pragma("unroll") for (int nt = 0; nt < 5; ++nt) bf[nt] = *(const half8*)(cur + (ofs) + nt * 2048);
+    if (!(VAR & 2)) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(cur + (ofs) + nt * 2048);
 #define LOAD_A(ofs, mh)                                                                               \
     if (!(VAR & 2)) _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) af[mt] = *(const half8*)(cur + (ofs) + ((mh) * 4 + mt) * 2048);
 #define ISSUE_N(sec)                                                                                  \
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     jn0 += kSched[0][sec]; jn1 += kSched[1][sec];
 #define MFMA_BLOCK(mh)                                                                                \
     __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int nt = 0; nt < 5; ++nt)                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                              \
             acc[nt][(mh) * 4 + mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[nt][(mh) * 4 + mt], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 #undef MFMA_BLOCK
 #undef FENCE
 
-    // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*128 + mt*16 + fr
+    // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*WN + nt*16 + 4*fg + r ; m = m0 + wr*128 + mt*16 + fr
     const long long zD = z * p.sD, zR = z * p.sR;
     if (p.splitk > 1) {
         float* ws = p.ws + (long long)ks * p.M * p.Npad;
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             const int m = m0 + wr * 128 + mt * 16 + fr;
             if (m < p.M) {
 #pragma unroll
-                for (int nt = 0; nt < 5; ++nt) {
-                    const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + wc * WN + nt * 16 + 4 * fg;
                     *(floatx4*)(ws + (long long)m * p.Npad + n) = acc[nt][mt];
                 }
             }
@@ -265,10 +269,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     if (p.epi == EPI_GEGLU_PAIR) {
         // weight rows interleaved pairwise: a lane's 4 consecutive n are (value_j, gate_j, value_j+1, gate_j+1), j = n/2
         const int half_n = p.N >> 1;
-        float bvv[5][2], bvg[5][2];
+        float bvv[NT][2], bvg[NT][2];
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) {
-            const int j = (n0 + wc * 80 + nt * 16 + 4 * fg) >> 1;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int j = (n0 + wc * WN + nt * 16 + 4 * fg) >> 1;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool ok = p.bias && j + r < half_n;
@@ -282,8 +286,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             const int m = m0 + wr * 128 + mt * 16 + fr;
             if (m < p.M) {
 #pragma unroll
-                for (int nt = 0; nt < 5; ++nt) {
-                    const int j = (n0 + wc * 80 + nt * 16 + 4 * fg) >> 1;
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int j = (n0 + wc * WN + nt * 16 + 4 * fg) >> 1;
                     if (j + 1 < half_n) {
                         typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
                         const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * gelu_erf(acc[nt][mt][1] + bvg[nt][0])),
@@ -297,10 +301,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         return;
     }
     {   // EPI_STD with N % 4 == 0 (checked on the host), one row group at a time so the 160 accumulators stay in registers
-        float bv[5][4];
+        float bv[NT][4];
 #pragma unroll
-        for (int nt = 0; nt < 5; ++nt) {
-            const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wc * WN + nt * 16 + 4 * fg;
 #pragma unroll
             for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
         }
@@ -309,14 +313,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         // two halves of 4 row groups: the 20 residual loads of a half are all in flight before the first use
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
-            half4 rr[4][5];
+            half4 rr[4][NT];
             if (R) {
 #pragma unroll
                 for (int mq = 0; mq < 4; ++mq) {
                     const int m = min(m0 + wr * 128 + (mh * 4 + mq) * 16 + fr, p.M - 1);
 #pragma unroll
-                    for (int nt = 0; nt < 5; ++nt) {
-                        const int n = min(n0 + wc * 80 + nt * 16 + 4 * fg, p.N - 4);
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int n = min(n0 + wc * WN + nt * 16 + 4 * fg, p.N - 4);
                         rr[mq][nt] = *(const half4*)(R + (long long)m * p.ldr + n);
                     }
                 }
@@ -327,8 +331,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
                 const int m = m0 + wr * 128 + mt * 16 + fr;
                 if (m < p.M) {
 #pragma unroll
-                    for (int nt = 0; nt < 5; ++nt) {
-                        const int n = n0 + wc * 80 + nt * 16 + 4 * fg;
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const int n = n0 + wc * WN + nt * 16 + 4 * fg;
                         if (n < p.N) {
                             float o[4];
 #pragma unroll
@@ -349,14 +353,17 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 }
 
 // ------------------------------------------------------------------------------------------ host side
+// block tile width for this problem: 320 where the padded width allows it, else 256, else 0 (not supported)
+int gemm_big_bn(const GemmArgs& a) { return a.Npad % 320 == 0 ? 320 : (a.Npad % 256 == 0 ? 256 : 0); }
+
 bool gemm_big_supported(const GemmArgs& a)
 {
     GemmArgs c = a;
     if (c.epi == EPI_GEGLU_PAIR) { c.epi = EPI_TRANS; }   // shared operand/alignment rules without gemm.hip's own epilogue constraints
     if (!gemm_mfma_supported(c)) return false;
-    if (a.Npad % BN || (a.epi != EPI_STD && a.epi != EPI_GEGLU_PAIR) || (a.N & 3)) return false;   // other epilogues stay on gemm.hip's kernel
+    if (!gemm_big_bn(a) || (a.epi != EPI_STD && a.epi != EPI_GEGLU_PAIR) || (a.N & 3)) return false;   // other epilogues stay on gemm.hip's kernel
     if (a.epi == EPI_GEGLU_PAIR && (a.ldd & 1)) return false;
-    // 32-bit byte offsets inside a 2 GiB descriptor window; 24-bit pixel index / row pitch for the mad
+    // 32-bit byte offsets inside a 2 GiB descriptor window
     const long long rowsA = a.taps == 9 ? (long long)(a.M / (a.Ho * a.Wo)) * (a.ups ? (a.Hi / 2) * (a.Wi / 2) : a.Hi * a.Wi) : a.M;
     if (rowsA >= (1 << 24) || a.lda0 * 2 >= (1 << 23) || a.lda1 * 2 >= (1 << 23) || a.Wi >= (1 << 16)) return false;
     if (rowsA * std::max(a.lda0, a.lda1) * 2 >= 0x7ff00000LL) return false;
@@ -364,28 +371,46 @@ bool gemm_big_supported(const GemmArgs& a)
     return true;
 }
 
-void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)
+template <bool CONV, bool UPS, int NT, int VAR = 0>
+static void launch_big_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
     static bool attr_set = false;
+    auto kern = gemm_big_kernel<CONV, UPS, NT, VAR>;
     if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(NT)));
         attr_set = true;
     }
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem_bytes(NT), ctx.stream, p);
+}
+
+void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)
+{
+    const int bn = p.Npad % 320 == 0 ? 320 : 256;
     p.nbm = cdiv(p.M, BM);
-    p.nbn = p.Npad / BN;
+    p.nbn = p.Npad / bn;
     dim3 grid(p.nbm * p.nbn, p.splitk, batch);
 #ifdef SDE_DIAG
     static const int var = getenv("SDE_BIGVAR") ? atoi(getenv("SDE_BIGVAR")) : 0;
-    if (conv && !p.ups && var) {
-#define DIAG(V) case V: { static bool s = false; if (!s) { HIP_CHECK(hipFuncSetAttribute((const void*)gemm_big_kernel<true, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES)); s = true; } \
-        hipLaunchKernelGGL((gemm_big_kernel<true, false, V>), grid, dim3(512), SMEM_BYTES, ctx.stream, p); return; }
-        switch (var) { DIAG(1) DIAG(2) DIAG(3) DIAG(8) DIAG(16) DIAG(32) DIAG(48) default: break; }
-#undef DIAG
+    if (conv && !p.ups && var && bn == 320) {
+        switch (var) {
+        case 1: launch_big_t<true, false, 5, 1>(ctx, p, grid); return;
+        case 2: launch_big_t<true, false, 5, 2>(ctx, p, grid); return;
+        case 3: launch_big_t<true, false, 5, 3>(ctx, p, grid); return;
+        case 8: launch_big_t<true, false, 5, 8>(ctx, p, grid); return;
+        case 16: launch_big_t<true, false, 5, 16>(ctx, p, grid); return;
+        case 32: launch_big_t<true, false, 5, 32>(ctx, p, grid); return;
+        case 48: launch_big_t<true, false, 5, 48>(ctx, p, grid); return;
+        default: break;
+        }
     }
 #endif
-    if (conv && p.ups) hipLaunchKernelGGL((gemm_big_kernel<true, true>), grid, dim3(512), SMEM_BYTES, ctx.stream, p);
-    else if (conv)     hipLaunchKernelGGL((gemm_big_kernel<true, false>), grid, dim3(512), SMEM_BYTES, ctx.stream, p);
-    else               hipLaunchKernelGGL((gemm_big_kernel<false, false>), grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+    if (bn == 320) {
+        if (conv && p.ups) launch_big_t<true, true, 5>(ctx, p, grid);
+        else if (conv)     launch_big_t<true, false, 5>(ctx, p, grid);
+        else               launch_big_t<false, false, 5>(ctx, p, grid);
+    } else {
+        if (conv && p.ups) launch_big_t<true, true, 4>(ctx, p, grid);
+        else if (conv)     launch_big_t<true, false, 4>(ctx, p, grid);
+        else               launch_big_t<false, false, 4>(ctx, p, grid);
+    }
 }

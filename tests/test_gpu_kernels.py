@@ -82,6 +82,9 @@ BIG_CASES = [
     (1, 30, 30, 256, 320, 1, 1, 0),     # linear, ragged M
     (1, 8, 8, 1280, 640, 3, 1, 0),      # long K (180 K-tiles): split-K slabs through the big kernel
     (1, 40, 40, 64, 320, 1, 1, 0),      # a single K-tile (prologue only)
+    (1, 32, 32, 128, 256, 3, 1, 0),     # 256x256 tile variant (VAE widths)
+    (1, 16, 16, 256, 512, 3, 1, 1),     # same, two column tiles, fused upsample
+    (2, 24, 24, 128, 256, 1, 1, 0),     # same, linear, ragged M
 ]
 
 
