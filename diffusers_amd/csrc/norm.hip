@@ -171,6 +171,66 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const h
     }
 }
 
+// Small tensors (deep UNet levels): one block per (image, group) holds the whole group in registers: one launch, x read
+// once, no workspace.  The two-pass path above costs two ~13 us launch/latency floors there for a few MB of data.
+// Needs cpg % 4 == 0 (8-byte chunks never straddle a group or the concat boundary) and HW*cpg/4 <= 256*GN_SMALL_MAX.
+#define GN_SMALL_MAX 24
+typedef _Float16 half4n __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void gn_small_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, int groups, float eps,
+                                                       const float* gamma, const float* beta, int silu, half_t* Y)
+{
+    __shared__ float red[2][4];
+    const int C = C0 + C1, cpg = C / groups, cq = cpg >> 2;   // 8-byte chunks per pixel in this group
+    const int g = blockIdx.x, nb = blockIdx.y, tid = threadIdx.x;
+    const int total = HW * cq;
+    const int c_base = g * cpg;
+    half4n v[GN_SMALL_MAX];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int u = 0; u < GN_SMALL_MAX; ++u) {
+        const int i = tid + u * 256;
+        if (i < total) {
+            const int px = i / cq, c = c_base + (i - px * cq) * 4;
+            const long long row = (long long)nb * HW + px;
+            const half_t* src = c < C0 ? X0 + row * C0 + c : X1 + row * C1 + (c - C0);
+            v[u] = *(const half4n*)src;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < GN_SMALL_MAX; ++u) {
+        if (tid + u * 256 < total) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float f = (float)v[u][j]; s += f; q += f * f; }
+        }
+    }
+    s = wave_sum(s); q = wave_sum(q);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = q; }
+    __syncthreads();
+    s = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    const float cnt = (float)cpg * (float)HW;
+    const float mean = s / cnt;
+    const float rstd = rsqrtf(fmaxf(q / cnt - mean * mean, 0.f) + eps);
+#pragma unroll
+    for (int u = 0; u < GN_SMALL_MAX; ++u) {
+        const int i = tid + u * 256;
+        if (i < total) {
+            const int px = i / cq, c = c_base + (i - px * cq) * 4;
+            const float4 ga = *(const float4*)(gamma + c), be = *(const float4*)(beta + c);
+            const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+            half4n o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = rstd * gg[j];
+                float y = (float)v[u][j] * a + (bb[j] - mean * a);   // same scale/shift form as the two-pass path
+                if (silu) y = y / (1.0f + __expf(-y));
+                o[j] = (half_t)y;
+            }
+            *(half4n*)(Y + ((long long)nb * HW + px) * C + c) = o;
+        }
+    }
+}
+
 static void gn_geometry(int C, int HW, int& TPP, int& OPT, int& PR, int& ppc, int& nchunks)
 {
     const int CX = C / 8;
@@ -202,7 +262,26 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
     float* part = a.ws;
     const double bytes = (double)a.NB * a.HW * C * 2.0;
     {
-        ProfScope ps(ctx, "groupnorm_stats", 0, bytes);
+        const int cpg = C / a.groups;
+        if (cpg % 4 == 0 && a.C0 % 4 == 0 && (long long)a.HW * (cpg / 4) <= 256LL * 16 &&   // beyond ~16 chunks per thread the two-pass path is faster (measured)
+           
+            ((reinterpret_cast<uintptr_t>(a.gamma) | reinterpret_cast<uintptr_t>(a.beta)) & 15) == 0) {
+            char nm[48];
+            static const bool shp = getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"));
+            if (shp) snprintf(nm, sizeof(nm), "gn1 HW%d C%d", a.HW, C); else snprintf(nm, sizeof(nm), "%s", a.silu ? "groupnorm_silu_fused_small" : "groupnorm_fused_small");
+            ProfScope ps(ctx, nm, 0, 2 * bytes);
+            hipLaunchKernelGGL(gn_small_kernel, dim3(a.groups, a.NB), dim3(256), 0, ctx.stream, a.X0, a.X1, a.C0, a.C1, a.HW, a.groups, a.eps,
+                               a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
+    static const bool shapes = getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"));
+    char nm_s[48] = "groupnorm_stats", nm_a[48];
+    snprintf(nm_a, sizeof(nm_a), "%s", a.silu ? "groupnorm_silu_apply" : "groupnorm_apply");
+    if (shapes) { snprintf(nm_s, sizeof(nm_s), "gnS HW%d C%d", a.HW, C); snprintf(nm_a, sizeof(nm_a), "gnA HW%d C%d", a.HW, C); }
+    {
+        ProfScope ps(ctx, nm_s, 0, bytes);
         const dim3 grid(nchunks, a.NB), block(256);
         const size_t lds = (size_t)2 * PR * C * sizeof(float);
 #define GN_STATS(O) hipLaunchKernelGGL(gn_stats_kernel<O>, grid, block, lds, ctx.stream, a.X0, a.X1, a.C0, a.C1, a.HW, a.groups, TPP, PR, ppc, nchunks, part)
@@ -210,7 +289,7 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
 #undef GN_STATS
     }
     {
-        ProfScope ps(ctx, a.silu ? "groupnorm_silu_apply" : "groupnorm_apply", 0, 2 * bytes);
+        ProfScope ps(ctx, nm_a, 0, 2 * bytes);
         // ~1024 blocks across the batch, at least 16 pixel rows each
         int bpi = std::max(1, std::min(cdiv(1024, a.NB), cdiv(a.HW, 16)));
         const int rpb = cdiv(a.HW, bpi);
@@ -222,11 +301,10 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
 }
 
 // ------------------------------------------------------------------------------------------ LayerNorm
-// one wave per LN_ROWS rows; the rows live in registers (<= LN_MAX_OCT octets per lane and row) for an exact two-pass
+// one wave per LN_ROWS rows (4 for long tensors, 1 when there are too few rows to fill the chip otherwise); the rows live in registers (<= LN_MAX_OCT octets per lane and row) for an exact two-pass
 // variance.  All loads of the wave's rows are issued before the first reduction (memory-level parallelism).
 #define LN_MAX_OCT 4
-#define LN_ROWS 4
-template <int NOCT>
+template <int NOCT, int LN_ROWS>
 __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* X, half_t* Y, int rows, int C, const float* gamma, const float* beta, float eps)
 {
     const int lane = threadIdx.x & 63;
@@ -291,13 +369,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* X, half_t*
 void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows, int C, const float* gamma, const float* beta, float eps)
 {
     SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
-    ProfScope ps(ctx, "layernorm", 0, 4.0 * rows * C);
+    char nm_l[48] = "layernorm";
+    if (getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"))) snprintf(nm_l, sizeof(nm_l), "ln M%d C%d", rows, C);
+    ProfScope ps(ctx, nm_l, 0, 4.0 * rows * C);
     const int noct = cdiv(C / 8, 64);
-    const dim3 grid(cdiv(rows, 4 * LN_ROWS)), block(256);
-    if (noct == 1)      hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
-    else if (noct == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
-    else if (noct == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
-    else                hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps);
+    const dim3 block(256);
+#define LN_LAUNCH(O, R) hipLaunchKernelGGL((layernorm_kernel<O, R>), dim3(cdiv(rows, 4 * R)), block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps)
+    if (rows >= 32768) {
+        if (noct == 1) LN_LAUNCH(1, 4); else if (noct == 2) LN_LAUNCH(2, 4); else if (noct == 3) LN_LAUNCH(3, 4); else LN_LAUNCH(4, 4);
+    } else {
+        if (noct == 1) LN_LAUNCH(1, 1); else if (noct == 2) LN_LAUNCH(2, 1); else if (noct == 3) LN_LAUNCH(3, 1); else LN_LAUNCH(4, 1);
+    }
+#undef LN_LAUNCH
     HIP_CHECK(hipGetLastError());
 }
 
