@@ -170,7 +170,12 @@ __global__ void repack_kernel(RepackDev a)
             int j = o < a.geglu_half ? o : o - a.geglu_half;
             row = a.geglu_pair ? 2 * j + (o < a.geglu_half ? 0 : 1) : 32 * (j >> 4) + (j & 15) + (o < a.geglu_half ? 0 : 16);
         }
-        a.dst[(long long)(a.dst_row0 + row) * a.Kdst + (long long)tap * a.Ipad + a.i0 + i] = (half_t)v;
+        // K order of a 3x3 weight row: 64-channel chunks outermost, then the 9 taps, then the channel inside the chunk
+        // (all taps of a chunk are consecutive K-tiles, so the im2col re-reads of an activation line hit L2; kernels.h)
+        const int c = a.i0 + i, taps = a.KH * a.KW;
+        const int ck = (taps > 1 && a.Ipad % 64 == 0) ? 64 : a.Ipad;
+        const long long kcol = ((long long)(c / ck) * taps + tap) * ck + c % ck;
+        a.dst[(long long)(a.dst_row0 + row) * a.Kdst + kcol] = (half_t)v;
     }
 }
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& r)

@@ -73,7 +73,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
 #pragma unroll
     for (int i = 0; i < BP; ++i) w_ptr[i] = Wp + (long long)(n0 + i * 32 + srow) * p.K + lchunk * 8;
 
-    const int Ctot = p.C0 + p.C1;
     const int nk_all = p.K >> 6;
     const int ks = blockIdx.y;
     const int kt0 = (int)((long long)nk_all * ks / p.splitk);
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
         char* sb = sa + A_BYTES;
         const int k0 = (kt0 + kt) << 6;
         int tap = 0, c0 = k0;
-        if (CONV) { tap = k0 / Ctot; c0 = k0 - tap * Ctot; }
+        if (CONV) { const int kt_abs = kt0 + kt; const int chunk = kt_abs / 9; tap = kt_abs - chunk * 9; c0 = chunk << 6; }   // chunk-major K (kernels.h)
         const half_t* src = A0; int ld = p.lda0; int cc = c0;
         if (c0 >= p.C0) { src = A1; ld = p.lda1; cc = c0 - p.C0; }
         int dy = 0, dx = 0;
@@ -234,20 +233,23 @@ __global__ void gemm_naive_kernel(GemmDev p)
                 pix = (long long)nb * p.Hs * p.Ws + (iy >> p.ups) * p.Ws + (ix >> p.ups);
             } else pix = m;
             if (!ok) continue;
-            const half_t* wr = Wp + (long long)wrow * p.K + tap * Ctot;
-            const half_t* wg = Wp + (long long)grow * p.K + tap * Ctot;
+            const half_t* wr = Wp + (long long)wrow * p.K;
+            const half_t* wg = Wp + (long long)grow * p.K;
+            const int ck = (p.taps > 1 && Ctot % 64 == 0) ? 64 : Ctot;   // K order: kernels.h
             const half_t* a0 = A0 + pix * p.lda0;
             for (int c = 0; c < p.C0; ++c) {
+                const int kc = ((c / ck) * p.taps + tap) * ck + c % ck;
                 float x = (float)a0[c];
-                s += x * (float)wr[c];
-                if (gg) sg += x * (float)wg[c];
+                s += x * (float)wr[kc];
+                if (gg) sg += x * (float)wg[kc];
             }
             if (p.C1) {
                 const half_t* a1 = A1 + pix * p.lda1;
                 for (int c = 0; c < p.C1; ++c) {
+                    const int cc = p.C0 + c, kc = ((cc / ck) * p.taps + tap) * ck + cc % ck;
                     float x = (float)a1[c];
-                    s += x * (float)wr[p.C0 + c];
-                    if (gg) sg += x * (float)wg[p.C0 + c];
+                    s += x * (float)wr[kc];
+                    if (gg) sg += x * (float)wg[kc];
                 }
             }
         }

@@ -110,12 +110,12 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         a_off1[j] = (unsigned)pix * (unsigned)(p.lda1 * 2) + lchunk16;
     }
     const unsigned w_off = (unsigned)((n0 + wid * 8 + srow) * p.K) * 2u + lchunk16;
-    const int Ctot = p.C0 + p.C1;
     const int w_part = 128 * p.K;   // byte stride between 64-row W parts
 
     // staging state of the K-tile currently being issued (wave-uniform scalars, recomputed once per K-tile)
+    // K order (kernels.h): conv K-tiles run chunk-major, kt = chunk*9 + tap, so consecutive tiles re-read the same lines
     int st_k0 = kt0 << 6, st_tap = 0, st_c = st_k0;
-    if (CONV) { st_tap = st_k0 / Ctot; st_c = st_k0 - st_tap * Ctot; }
+    if (CONV) { st_tap = kt0 % 9; st_c = (kt0 / 9) << 6; }
     bool st_second = false;      // the K-tile's channels come from the second source of a concat
     unsigned st_bit = 1u;        // 1 << tap
     int st_add = 0;              // byte offset of (tap, channel) relative to the window centre (not UPS: includes the tap shift)
@@ -133,8 +133,9 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
     };
     stage_scalars();
     auto stage_advance = [&]() {
-        st_k0 += 64; st_c += 64;
-        if (CONV && st_c >= Ctot) { st_c = 0; ++st_tap; }
+        st_k0 += 64;
+        if (CONV) { if (++st_tap == 9) { st_tap = 0; st_c += 64; } }
+        else st_c += 64;
         stage_scalars();
     };
     // issue staging part j of the current staging K-tile into buffer `buf`

@@ -2,7 +2,8 @@
 //
 // Layout conventions inside the engine:
 //   activations  : fp16, NHWC == [rows = NB*H*W][C] row-major ("token-major"), C % 8 == 0
-//   weights      : fp16, [Npad][K] row-major with K = taps*Cin in (ky,kx,cin) order (OHWI)
+//   weights      : fp16, [Npad][K] row-major, K = taps*Cin.  3x3: K index = ((cin/64)*9 + tap)*64 + cin%64 when Cin % 64 == 0
+//                  (chunk-major: the 9 taps of a 64-channel chunk are consecutive K-tiles), else tap*Cin + cin
 //   accumulators : fp32
 #pragma once
 #include "common.h"
