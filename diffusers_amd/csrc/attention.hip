@@ -38,7 +38,10 @@ struct AttnDev {
 
 // ONES: the head dim leaves a spare column in the last 16-wide V tile (d < 16*DVT); it is filled with 1.0 so the PV product
 // also accumulates the softmax denominator (row DVT*16-1 of O^T) and the VALU row sum disappears.
-template <int DQK, int DVT, bool ONES>
+// FOLD: the head dim leaves spare columns in the score product (d < DQK).  Q is pre-multiplied by scale*log2(e) and two
+// spare columns carry -(running max) as an fp16 hi+lo pair against 1.0 in K, so the MFMA delivers s*c - m*c directly and the
+// per-score VALU work is max + exp2 + cvt (the kernel is VALU-issue-bound at d = 40).
+template <int DQK, int DVT, bool ONES, bool FOLD>
 __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(AttnDev p)
 {
     constexpr int KROW = DQK + 8;        // padded K-tile row (elements)
@@ -68,8 +71,14 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             int q = q0 + qt * 16 + fr, c = (ks * 4 + fg) * 8;
             half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (q < p.Sq && c < d) v = *(const half8*)(Qb + (long long)q * p.ldq + c);
+            if (FOLD) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * csl);
+            }
             qf[qt][ks] = v;
         }
+    // FOLD: column d (chunk ks_e, lane group fg_e) of Q holds -M_hi, column d+1 -M_lo (M = running max, log2 units); zero until the first tile is done
+    const int ks_e = d >> 5, fg_e = (d >> 3) & 3;
 
     floatx4 o[DVT][2];
 #pragma unroll
@@ -119,7 +128,11 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
     // pad columns (>= d) never change: written once.  ONES: the very last V column holds 1.0 (softmax denominator).
 #pragma unroll
     for (int i = 0; i < KN; ++i)
-        if (kcol[i] < 0 && klds[i] >= 0) *(half8*)(sK + klds[i]) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (kcol[i] < 0 && klds[i] >= 0) {
+            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (FOLD && klds[i] - krow[i] * KROW == d) { z[0] = (half_t)1.0f; z[1] = (half_t)1.0f; }   // the two max-carrying columns
+            *(half8*)(sK + klds[i]) = z;
+        }
 #pragma unroll
     for (int i = 0; i < VN; ++i)
         if (vcol[i] < 0 && vlds[i] >= 0) {
@@ -161,6 +174,32 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             // deferred rescale: raise the running max only when it grows by more than THR (log2 units)
+            if (FOLD) {
+                // scores are already s*c - M_old (M_old = 0 before the first tile): mx is the growth of the maximum
+                const bool first = mrow[qt] == -INFINITY;
+                const bool grow = mx > ATTN_RESCALE_THR || first;
+                if (__any(grow)) {
+                    const float delta = grow ? mx : 0.f;
+                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                    mrow[qt] = (first ? 0.f : mrow[qt]) + delta;
+                    lrow[qt] *= alpha;
+#pragma unroll
+                    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+#pragma unroll
+                    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[kt][qt][r] -= delta;
+                    const half_t hi = (half_t)(-mrow[qt]);
+                    const half_t lo = (half_t)(-mrow[qt] - (float)hi);
+                    if (fg == fg_e) {
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks)
+                            if (ks == ks_e) { qf[qt][ks][0] = hi; qf[qt][ks][1] = lo; }
+                    }
+                }
+            } else {
             const bool grow = mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY;
             if (__any(grow)) {
                 float mnew = grow ? mx : mrow[qt];
@@ -172,6 +211,7 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
                 for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+            }
             }
         }
         // phase 2 (straight line): V^T fragments, then exp / PV per q-tile so that the second tile's exponentials can
@@ -206,7 +246,7 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float e = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], csl, -mc));
+                    float e = FOLD ? __builtin_amdgcn_exp2f(s[kt][qt][r]) : __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][qt][r], csl, -mc));
                     if (!ONES) sum += e;
                     pf[kt >> 1][(kt & 1) * 4 + r] = (half_t)e;
                 }
@@ -309,8 +349,16 @@ template <int DQK, int DVT>
 static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
 {
     dim3 grid(cdiv(p.Sq, 128), p.heads, p.NB);
-    if (p.d < DVT * 16) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true>), grid, dim3(256), 0, ctx.stream, p);
-    else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false>), grid, dim3(256), 0, ctx.stream, p);
+    static const int fold_env = getenv("SDE_ATTN_FOLD") ? atoi(getenv("SDE_ATTN_FOLD")) : 1;   // tuning hook
+    const bool fold = fold_env && p.d < DQK && DVT <= 4;    // needs two spare score-product columns; wider heads run out of VGPRs (measured slower)
+    const bool ones = p.d < DVT * 16;
+    if (fold) {
+        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, true>), grid, dim3(256), 0, ctx.stream, p);
+        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, true>), grid, dim3(256), 0, ctx.stream, p);
+    } else {
+        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, false>), grid, dim3(256), 0, ctx.stream, p);
+        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, false>), grid, dim3(256), 0, ctx.stream, p);
+    }
 }
 
 void launch_attention(const LaunchCtx& ctx, const AttnArgs& a)
