@@ -155,16 +155,26 @@ def main():
                                      tflops=round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1) if s["flops"] and s["total_ms"] else None,
                                      gbs=round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1) if s["bytes"] and s["total_ms"] else None))
         dom = max(stats, key=lambda s: s["total_ms"])
+        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # figure comes from the committed rocprofv3 --pmc passes over this same workload (profiles/r1_pmc_traffic.json)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+            for key, v in pmc.items():
+                if dom["name"] in key.replace("(", "+").split("+"):
+                    traffic = round((v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"]) * 1e6)
+        except Exception:
+            traffic = None
         if dom["flops"] > 0:
             ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": None, "launches": dom["launches"],
+                    "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": traffic, "launches": dom["launches"],
                     "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2),
                     "flop_per_launch": dom["flops"] / dom["launches"], "profiled_step_ms": round(rp.total_ms, 2)}
         else:
             ach = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
             roof = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None, "launches": dom["launches"],
+                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "launches": dom["launches"],
                     "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2)}
 
     total_images = world * B * args.steps

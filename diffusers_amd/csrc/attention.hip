@@ -52,8 +52,19 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int nb = blockIdx.z, head = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + wid * 32;
+    // XCD-aware block order (blocks b, b+8, ... share an XCD and its L2): every XCD gets a contiguous run of the flat
+    // (batch, head, q-block) index, so the q-blocks that re-read one head's K/V sit behind one L2 (PMC: 3x over-fetch before)
+    int nb, head, qb;
+    {
+        const int nqb = gridDim.x, per_head = nqb, total = nqb * gridDim.y * gridDim.z;
+        int bid = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q8 = total >> 3, r8 = total & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        qb = bid % per_head;
+        const int hb = bid / per_head;
+        head = hb % gridDim.y; nb = hb / gridDim.y;
+    }
+    const int q0 = qb * 128 + wid * 32;
     const int d = p.d;
     const float csl = p.scale_log2e;
 
