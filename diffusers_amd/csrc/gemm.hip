@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / p.nbn, tn = bid - tm * p.nbn;
+    // each XCD re-reads whatever its tiles share: keep the larger operand's panel behind one L2 (host picks, launch_gemm)
+    const int tm = p.colmajor ? bid % p.nbm : bid / p.nbn, tn = p.colmajor ? bid / p.nbm : bid - (bid / p.nbn) * p.nbn;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const half_t* A0 = p.A0 + z * p.sA;
@@ -276,6 +277,12 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
     p.epi = a.epi; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
     p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr;
+    // fabric reads ~ A + 8*W with column tiles fastest, 8*A + W with row tiles fastest (8 XCDs, each with its own L2)
+    {
+        static const int cm_env = getenv("SDE_COLMAJOR") ? atoi(getenv("SDE_COLMAJOR")) : -1;   // tuning hook
+        const double bytesA = (double)a.M * (a.C0 + a.C1) * 2.0 / (a.stride * a.stride) * (a.ups ? 0.25 : 1.0), bytesW = (double)a.Npad * a.K * 2.0;
+        p.colmajor = cm_env >= 0 ? cm_env : (bytesW > 4.0 * bytesA ? 1 : 0);   // measured: only the 8x8 level gains (3-4 %); near the break-even it is a wash
+    }
     return p;
 }
 

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid / p.nbn, tn = bid - tm * p.nbn;
+    // each XCD re-reads whatever its tiles share: keep the larger operand's panel behind one L2 (host picks, launch_gemm)
+    const int tm = p.colmajor ? bid % p.nbm : bid / p.nbn, tn = p.colmajor ? bid / p.nbm : bid - (bid / p.nbn) * p.nbn;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int nk_all = p.K >> 6;

@@ -20,6 +20,7 @@ struct GemmDev {
     long long sA, sW, sD, sR;
     const half_t* zeros;
     int nbm, nbn;
+    int colmajor;            // tile order inside an XCD's contiguous chunk: 0 = column tile fastest (A panel stays in L2), 1 = row tile fastest (W panel stays in L2)
     int splitk; float* ws;   // splitk > 1: raw fp32 partial tiles go to ws[ks][M][Npad], reduced by splitk_reduce_kernel
 };
 
