@@ -268,13 +268,23 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         }
         return;
     }
+    // Results go through the wave's own 18 KiB slice of the (now idle) staging LDS so that global stores are whole 16-byte
+    // chunks in row order (80-160 B runs per row) instead of 4/8-byte pieces scattered over 16 rows per instruction.
+    // The slice is private to the wave: only wave-level ordering is needed (s_waitcnt + wave_barrier), no s_barrier.
+    char* const wlds = smem + wid * (smem_bytes(NT) / 8);
+    const bool vec_ok = (p.ldd & 7) == 0;   // 16-byte aligned rows (host guarantees N % 8 == 0 on this path)
     if (p.epi == EPI_GEGLU_PAIR) {
         // weight rows interleaved pairwise: a lane's 4 consecutive n are (value_j, gate_j, value_j+1, gate_j+1), j = n/2
+        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+        constexpr int OW = WN / 2;              // output columns per wave
+        constexpr int PITCH = OW * 2 + 16;      // LDS row pitch (bytes)
+        constexpr int CH = OW * 2 / 16;         // 16-byte chunks per row
         const int half_n = p.N >> 1;
+        const int j0 = (n0 + wc * WN) >> 1;
         float bvv[NT][2], bvg[NT][2];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            const int j = (n0 + wc * WN + nt * 16 + 4 * fg) >> 1;
+            const int j = j0 + nt * 8 + 2 * fg;
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const bool ok = p.bias && j + r < half_n;
@@ -284,25 +294,38 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         }
         half_t* D = p.D + zD;
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            const int m = m0 + wr * 128 + mt * 16 + fr;
-            if (m < p.M) {
+        for (int mh = 0; mh < 2; ++mh) {
+#pragma unroll
+            for (int mq = 0; mq < 4; ++mq) {
+                const int mt = mh * 4 + mq;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int j = (n0 + wc * WN + nt * 16 + 4 * fg) >> 1;
-                    if (j + 1 < half_n) {
-                        typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-                        const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * gelu_erf(acc[nt][mt][1] + bvg[nt][0])),
-                                           (half_t)((acc[nt][mt][2] + bvv[nt][1]) * gelu_erf(acc[nt][mt][3] + bvg[nt][1]))};
-                        *(half2_t*)(D + (long long)m * p.ldd + j) = h;
-                    }
+                    const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * gelu_erf(acc[nt][mt][1] + bvg[nt][0])),
+                                       (half_t)((acc[nt][mt][2] + bvv[nt][1]) * gelu_erf(acc[nt][mt][3] + bvg[nt][1]))};
+                    *(half2_t*)(wlds + (mq * 16 + fr) * PITCH + (nt * 8 + 2 * fg) * 2) = h;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
+                const int m = m0 + wr * 128 + mh * 64 + row, j = j0 + ch * 8;
+                const half8 v = *(const half8*)(wlds + row * PITCH + ch * 16);
+                if (m < p.M && j < half_n) {
+                    if (vec_ok && j + 8 <= half_n) *(half8*)(D + (long long)m * p.ldd + j) = v;
+                    else for (int e = 0; e < 8 && j + e < half_n; ++e) D[(long long)m * p.ldd + j + e] = v[e];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
-    {   // EPI_STD with N % 4 == 0 (checked on the host), one row group at a time so the 160 accumulators stay in registers
+    {   // EPI_STD, 32 rows (two row groups) at a time: fp32 in LDS so the residual is added before the single rounding
+        constexpr int PITCH = WN * 4 + 32;      // LDS row pitch (bytes, fp32)
+        constexpr int CH = WN / 8;              // 8-column chunks per row (32 B in LDS, 16 B in memory)
+        constexpr int NI = 32 * CH / 64;        // chunks per lane and step
         float bv[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -312,44 +335,49 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         }
         const half_t* R = p.R ? p.R + zR : nullptr;
         half_t* D = p.D + zD;
-        // two halves of 4 row groups: the 20 residual loads of a half are all in flight before the first use
+        const bool rvec_ok = R && (p.ldr & 7) == 0;
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
-            half4 rr[4][NT];
+        for (int ms = 0; ms < 4; ++ms) {
+            // residual chunks of these 32 rows, in flight while the accumulators go through LDS
+            half8 rr[NI];
             if (R) {
 #pragma unroll
-                for (int mq = 0; mq < 4; ++mq) {
-                    const int m = min(m0 + wr * 128 + (mh * 4 + mq) * 16 + fr, p.M - 1);
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int n = min(n0 + wc * WN + nt * 16 + 4 * fg, p.N - 4);
-                        rr[mq][nt] = *(const half4*)(R + (long long)m * p.ldr + n);
-                    }
+                for (int i = 0; i < NI; ++i) {
+                    const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
+                    const int m = min(m0 + wr * 128 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
+                    if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
+                    else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
                 }
             }
 #pragma unroll
-            for (int mq = 0; mq < 4; ++mq) {
-                const int mt = mh * 4 + mq;
-                const int m = m0 + wr * 128 + mt * 16 + fr;
-                if (m < p.M) {
+            for (int mq = 0; mq < 2; ++mq) {
+                const int mt = ms * 2 + mq;
 #pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        const int n = n0 + wc * WN + nt * 16 + 4 * fg;
-                        if (n < p.N) {
-                            float o[4];
+                for (int nt = 0; nt < NT; ++nt) {
+                    floatx4 o;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
-                            if (R) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) o[r] += (float)rr[mq][nt][r];
-                            }
-                            const half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-                            *(half4*)(D + (long long)m * p.ldd + n) = h;
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
+                    *(floatx4*)(wlds + (mq * 16 + fr) * PITCH + (nt * 16 + 4 * fg) * 4) = o;
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
+                const int m = m0 + wr * 128 + ms * 32 + row, n = n0 + wc * WN + ch * 8;
+                const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
+                const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                half8 v;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (half_t)(R ? f[e] + (float)rr[i][e] : f[e]);
+                if (m < p.M && n < p.N) {
+                    if (vec_ok && n + 8 <= p.N) *(half8*)(D + (long long)m * p.ldd + n) = v;
+                    else for (int e = 0; e < 8 && n + e < p.N; ++e) D[(long long)m * p.ldd + n + e] = v[e];
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
