@@ -769,7 +769,7 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
         std::lock_guard<std::mutex> lk(e->mu);
         engine_activate(e);
-        LaunchCtx ctx = e->ctx; ctx.force_naive = naive == 1; ctx.force_big = naive == 2;   // 0 fast, 1 plain, 2 force the 256x320 kernel
+        LaunchCtx ctx = e->ctx; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3;   // 0 fast, 1 plain, 2 / 3 force the 256x320 / 256x160 kernel
         const int taps = ksize * ksize;
         const int Hv = upsample ? 2 * Hi : Hi, Wv = upsample ? 2 * Wi : Wi;
         const int Ho = ksize == 3 ? (Hv - 1) / stride + 1 : Hv, Wo = ksize == 3 ? (Wv - 1) / stride + 1 : Wv;

@@ -263,6 +263,8 @@ __global__ void gemm_naive_kernel(GemmDev p)
 struct GemmDev;
 bool gemm_big_supported(const GemmArgs& a);                                        // gemm_big.hip
 int gemm_big_bn(const GemmArgs& a);
+bool gemm_mid_supported(const GemmArgs& a);                                        // gemm_mid.hip
+void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 
 int gemm_npad(int N) { return (N % 160 == 0 || N % 128 == 0) ? N : round_up(N, 128); }
@@ -276,7 +278,7 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     p.Hs = a.ups ? a.Hi / 2 : a.Hi; p.Ws = a.ups ? a.Wi / 2 : a.Wi;
     p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
     p.epi = a.epi; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
-    p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr;
+    p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr; p.stamps = nullptr;
     // fabric reads ~ A + 8*W with column tiles fastest, 8*A + W with row tiles fastest (8 XCDs, each with its own L2)
     {
         static const int cm_env = getenv("SDE_COLMAJOR") ? atoi(getenv("SDE_COLMAJOR")) : -1;   // tuning hook
@@ -354,7 +356,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
     const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (a.R ? 2 : 1)) * 2.0 * a.batch;
     static const int big_env = getenv("SDE_BIG") ? atoi(getenv("SDE_BIG")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
-    if (!ctx.force_naive && big_env && gemm_big_supported(a)) {
+    if (!ctx.force_naive && big_env && !ctx.force_mid && gemm_big_supported(a)) {
         // 8-wave 256x320 tiles, one block per CU: worth it once the grid (with split-K on long K) covers most of the chip
         const int tiles = cdiv(a.M, 256) * (a.Npad / gemm_big_bn(a)) * a.batch, nk = a.K >> 6;
         int sk = 1;
@@ -367,6 +369,45 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma_256x320" : (a.epi == EPI_GEGLU_PAIR ? "gemm_geglu_mfma_256x320" : "gemm_mfma_256x320"), a, "B"), flops, bytes);
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
             launch_gemm_big(ctx, p, a.batch, a.taps == 9);
+            if (sk > 1) {
+                long long total = (long long)p.M * (p.Npad >> 2);
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);
+            }
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
+    static const int mid_env = getenv("SDE_MID") ? atoi(getenv("SDE_MID")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
+    if (!ctx.force_naive && mid_env && !ctx.force_big && gemm_mid_supported(a)) {
+        // 8-wave 256x160 tiles with a 3-deep ring: the 32x32 / 16x16 UNet levels (one block per CU)
+        const int tiles = cdiv(a.M, 256) * (a.Npad / 160) * a.batch, nk = a.K >> 6;
+        int sk = 1;
+        if (a.batch == 1 && ctx.splitk_ws && tiles < 192 && nk >= 64) {
+            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 32), 2);
+            if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
+            while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;
+        }
+        if (mid_env == 2 || ctx.force_mid || tiles * sk >= 192) {
+            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma_256x160" : "gemm_mfma_256x160", a, "M"), flops, bytes);
+            p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
+#ifdef SDE_DIAG
+            static const bool stamps = getenv("SDE_STAMPS") && atoi(getenv("SDE_STAMPS"));
+            if (stamps && sk == 1) p.stamps = (unsigned*)ctx.splitk_ws;
+#endif
+            launch_gemm_mid(ctx, p, a.batch, a.taps == 9);
+#ifdef SDE_DIAG
+            if (p.stamps) {
+                unsigned h[65];
+                HIP_CHECK(hipStreamSynchronize(ctx.stream));
+                HIP_CHECK(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[stamps] M=%d N=%d K=%d: cycles per K-tile and wave: L0 | wait B | M0 | wait B | L1(+vmcnt g1) | wait B | M1(+vmcnt g0) | wait B\n", a.M, a.N, a.K);
+                for (int w = 0; w < 8; ++w) {
+                    fprintf(stderr, "  wave %d:", w);
+                    for (int i = 0; i < 8; ++i) fprintf(stderr, " %7.1f", (double)h[w * 8 + i] / h[64]);
+                    fprintf(stderr, "\n");
+                }
+            }
+#endif
             if (sk > 1) {
                 long long total = (long long)p.M * (p.Npad >> 2);
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);

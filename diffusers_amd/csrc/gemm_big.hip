@@ -236,11 +236,11 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         FENCE();
         if (wr == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves 4-7: last issue was in L2, two sections ago
         BAR(); FENCE();
+        if (more) stage_advance();   // the next tile's scalar address work rides under the MFMAs (all of this tile's issues are done)
         MFMA_BLOCK(0)
         FENCE();
         if (wr == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // waves 0-3: last issue at the latest in L3, one MFMA section ago
         BAR(); FENCE();
-        if (more) stage_advance();
     }
 #undef BAR
     if (wr == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7

@@ -21,6 +21,7 @@ struct GemmDev {
     const half_t* zeros;
     int nbm, nbn;
     int colmajor;            // tile order inside an XCD's contiguous chunk: 0 = column tile fastest (A panel stays in L2), 1 = row tile fastest (W panel stays in L2)
+    unsigned* stamps;        // diagnostic builds (-DSDE_DIAG): per-wave section cycle sums of one block, else null
     int splitk; float* ws;   // splitk > 1: raw fp32 partial tiles go to ws[ks][M][Npad], reduced by splitk_reduce_kernel
 };
 

@@ -1,0 +1,335 @@
+// gemm_mid.hip — 8-wave 256x160x64 fp16 GEMM / implicit-GEMM convolution with a 3-deep LDS ring, for gfx950 (MI355X).
+//
+// Same contract as gemm.hip / gemm_big.hip.  It takes the shapes between the two: the 32x32 and 16x16 UNet levels
+// (M = 16384 / 4096 at batch 16), whose grids cannot fill 256 CUs with 256x320 tiles but where the 4-wave 128x160 kernel
+// keeps the global->LDS path ~90 % busy.  A 256x160 tile needs 65 % of that path and gives 256 blocks at M=16384, N=640.
+//
+// Structure:
+//   * 512 threads = 8 waves as 4 (M) x 2 (N); wave tile 64 x 80 = 4 x 5 MFMA 16x16x32 tiles (80 accumulator VGPRs),
+//     D^T = W * A^T as in the other kernels.
+//   * LDS: 3 K-tile buffers x (256 + 160) rows x 128 B = 156 KiB, filled by buffer_load_dwordx4 ... lds (range-checked
+//     padding, source-side XOR swizzle).  The ring is three deep because a K-tile is only two phases long here: loads run
+//     two tiles ahead and are retired with a COUNTED s_waitcnt vmcnt(N) that leaves the newest tile in flight.
+//   * Each K-tile is 2 phases (k-halves) of {9 ds_read_b128 + load issue | barrier | 20 MFMA | barrier}; waves 4-7 run one
+//     barrier behind waves 0-3 (ping-pong on every SIMD, as in gemm_big.hip).
+//   * Buffer reuse: tile t+2 goes into the buffer of tile t-1.  Waves 4-7 finish reading it one interval into tile t, so
+//     waves 0-3 may only stage rows nobody else reads (their own A rows 0-127) in their first load section.
+#include "gemm_common.h"
+
+#include <algorithm>
+
+namespace {
+constexpr int BM = 256, BN = 160, WN = 80, NT = 5, MT = 4;
+constexpr int A_BYTES = BM * 128, STAGE = A_BYTES + BN * 128;       // 53,248 B per K-tile
+constexpr int SMEM_BYTES = 3 * STAGE;                                // 159,744 B
+constexpr unsigned OOB = 0x80000000u;
+constexpr int RSRC_FLAGS = 0x00020000;
+}  // namespace
+
+// staging parts of one K-tile: 0-3 = A rows 64j..64j+63, 4-5 = W rows 0-63 / 64-127, 6 = W rows 128-159 (waves 0-3 only)
+template <bool CONV, bool UPS>
+__global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2;
+    const int z = blockIdx.z;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int nwg = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = p.colmajor ? bid % p.nbm : bid / p.nbn, tn = p.colmajor ? bid / p.nbm : bid - (bid / p.nbn) * p.nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int nk_all = p.K >> 6;
+    const int ks = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * ks / p.splitk);
+    const int nk = (int)((long long)nk_all * (ks + 1) / p.splitk) - kt0;
+
+    const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A0 + z * p.sA), 0, OOB, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((p.A1 ? p.A1 : p.A0) + z * p.sA), 0, OOB, RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + z * p.sW), 0, OOB, RSRC_FLAGS);
+
+    // ---- staging geometry (as gemm_big.hip): wave w stages rows 8w..8w+7 of every 64-row part
+    const int srow = lane >> 3;
+    const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
+    unsigned a_off0[4], a_off1[4], a_mask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + j * 64 + wid * 8 + srow;
+        const bool ok = m < p.M;
+        int pix = m;
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int nb = m / hw, rem = m - nb * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int cy = oy * p.stride, cx = ox * p.stride;
+            unsigned mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                if (ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mask |= 1u << t;
+            }
+            mask |= (unsigned)(cy & 1) << 9 | (unsigned)(cx & 1) << 10;
+            a_mask[j] = mask;
+            pix = nb * p.Hs * p.Ws + (cy >> (UPS ? 1 : 0)) * p.Ws + (cx >> (UPS ? 1 : 0));
+        } else {
+            a_mask[j] = ok ? 1u : 0u;
+        }
+        a_off0[j] = (unsigned)pix * (unsigned)(p.lda0 * 2) + lchunk16;
+        a_off1[j] = (unsigned)pix * (unsigned)(p.lda1 * 2) + lchunk16;
+    }
+    const unsigned w_off = (unsigned)((n0 + wid * 8 + srow) * p.K) * 2u + lchunk16;
+    const int w_part = 128 * p.K;
+
+    // staging state of the K-tile currently being issued (K order: kernels.h)
+    int st_k0 = kt0 << 6, st_tap = 0, st_c = st_k0;
+    if (CONV) { st_tap = kt0 % 9; st_c = (kt0 / 9) << 6; }
+    bool st_second = false;
+    unsigned st_bit = 1u;
+    int st_add = 0, st_ld2 = 0, st_ey0 = 0, st_ey1 = 0, st_ex0 = 0, st_ex1 = 0;
+    auto stage_scalars = [&]() {
+        st_second = st_c >= p.C0;
+        const int ld2 = (st_second ? p.lda1 : p.lda0) * 2;
+        st_add = (st_second ? st_c - p.C0 : st_c) * 2;
+        if (CONV) {
+            const int dy = st_tap / 3, dx = st_tap - dy * 3;
+            st_bit = 1u << st_tap;
+            if (UPS) { st_ld2 = ld2; st_ey0 = -(dy == 0); st_ey1 = (dy == 2); st_ex0 = -(dx == 0); st_ex1 = (dx == 2); }
+            else st_add += ((dy - 1) * p.Ws + (dx - 1)) * ld2;
+        }
+    };
+    stage_scalars();
+    auto stage_advance = [&]() {
+        st_k0 += 64;
+        if (CONV) { if (++st_tap == 9) { st_tap = 0; st_c += 64; } }
+        else st_c += 64;
+        stage_scalars();
+    };
+    auto issue = [&](int j, int buf) {
+        char* dst = smem + buf * STAGE + (j < 4 ? j * 8192 : A_BYTES + (j - 4) * 8192) + wid * 1024;
+        if (j < 4) {
+            unsigned voff = (st_second ? a_off1[j] : a_off0[j]) + (unsigned)st_add;
+            if (CONV && UPS) {
+                const int ey = (a_mask[j] >> 9) & 1 ? st_ey1 : st_ey0;
+                const int ex = (a_mask[j] >> 10) & 1 ? st_ex1 : st_ex0;
+                voff += (unsigned)(__mul24(__mul24(ey, p.Ws) + ex, st_ld2));
+            }
+            voff = (a_mask[j] & st_bit) ? voff : OOB;
+            if (st_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, LDS_PTR(dst), 16, voff, 0, 0, 0);
+            else           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
+        } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, (j - 4) * w_part + st_k0 * 2, 0, 0);
+        }
+    };
+    // all parts of one K-tile (prologue)
+    auto issue_all = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) issue(j, buf);
+        if (grp == 0) issue(6, buf);
+    };
+
+    // ---- fragment read addresses (swizzled): A rows wr*64 + mt*16 + fr, W rows wc*80 + nt*16 + fr
+    const int swz0 = ((fg) ^ (fr & 7)) << 4, swz1 = ((4 + fg) ^ (fr & 7)) << 4;
+    const int a_rd0 = (wr * 64 + fr) * 128 + swz0, a_rd1 = (wr * 64 + fr) * 128 + swz1;
+    const int b_rd0 = A_BYTES + (wc * WN + fr) * 128 + swz0, b_rd1 = A_BYTES + (wc * WN + fr) * 128 + swz1;
+
+    floatx4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 bf[NT], af[MT];
+
+    // waves 0-3 have 7 loads per K-tile in flight, waves 4-7 have 6: the counted wait leaves exactly the newest tile's
+#define WAIT_OLDER()                                                                         \
+    do {                                                                                      \
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                        \
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                 \
+    } while (0)
+
+    // ---- prologue: K-tiles 0 and 1 into buffers 0 and 1
+    issue_all(0);
+    stage_advance();
+    if (nk > 1) { issue_all(1); stage_advance(); WAIT_OLDER(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+
+#define LOAD_FRAGS(bo, ao)                                                                            \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(cur + (bo) + nt * 2048);  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = *(const half8*)(cur + (ao) + mt * 2048);
+#define MFMA_BLOCK()                                                                                  \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[nt][mt], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+
+#ifdef SDE_DIAG
+    // in-kernel stamps (diagnostic build only): cycles per wave spent in each section of the two phases, summed over K-tiles
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+    unsigned st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[i] += (unsigned)(t_ - st_prev); st_prev = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+    int cb = 0;   // ring slot of the tile being computed
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* cur = smem + cb * STAGE;
+        const int nb_ = cb == 0 ? 2 : cb - 1;          // slot of tile kt+2 == slot of tile kt-1
+        const bool more2 = kt + 2 < nk;
+        // phase 0 (k-half 0).  Load section L0: waves 0-3 may only overwrite rows nobody else reads (A rows 0-127).
+        LOAD_FRAGS(b_rd0, a_rd0)
+        if (more2) {
+            if (grp == 0) { issue(0, nb_); issue(1, nb_); }
+            else { issue(0, nb_); issue(1, nb_); issue(2, nb_); }
+        }
+        FENCE(); STAMP(0); __builtin_amdgcn_s_barrier(); STAMP(1); FENCE();
+        if (more2 && grp == 0) issue(6, nb_);
+        MFMA_BLOCK()
+        FENCE(); STAMP(2); __builtin_amdgcn_s_barrier(); STAMP(3); FENCE();
+        // phase 1 (k-half 1)
+        LOAD_FRAGS(b_rd1, a_rd1)
+        if (more2) {
+            if (grp == 0) { issue(2, nb_); issue(3, nb_); issue(4, nb_); issue(5, nb_); }
+            else { issue(3, nb_); issue(4, nb_); issue(5, nb_); }
+        }
+        FENCE();
+        if (grp == 1) { if (more2) WAIT_OLDER(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // tile kt+1 landed
+        STAMP(4); __builtin_amdgcn_s_barrier(); STAMP(5); FENCE();
+        if (more2) stage_advance();   // scalar work of the next tile's addresses rides under the MFMAs
+        MFMA_BLOCK()
+        FENCE();
+        if (grp == 0) { if (more2) WAIT_OLDER(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        STAMP(6); __builtin_amdgcn_s_barrier(); STAMP(7); FENCE();
+        cb = cb == 2 ? 0 : cb + 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7
+#ifdef SDE_DIAG
+    if (p.stamps && blockIdx.x == 8 && lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p.stamps[wid * 8 + i] = st_sum[i];
+        if (wid == 0) p.stamps[64] = nk;
+    }
+#endif
+#undef STAMP
+#undef LOAD_FRAGS
+#undef MFMA_BLOCK
+#undef FENCE
+#undef WAIT_OLDER
+
+    // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
+    const long long zD = z * p.sD, zR = z * p.sR;
+    if (p.splitk > 1) {
+        float* ws = p.ws + (long long)ks * p.M * p.Npad;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wr * 64 + mt * 16 + fr;
+            if (m < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + wc * WN + nt * 16 + 4 * fg;
+                    *(floatx4*)(ws + (long long)m * p.Npad + n) = acc[nt][mt];
+                }
+            }
+        }
+        return;
+    }
+    // EPI_STD through the wave's own LDS slice (see gemm_big.hip): fp32 staging, 16-byte row-order stores
+    char* const wlds = smem + wid * (SMEM_BYTES / 8);
+    const bool vec_ok = (p.ldd & 7) == 0;
+    constexpr int PITCH = WN * 4 + 32, CH = WN / 8, NI = 32 * CH / 64;
+    float bv[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wc * WN + nt * 16 + 4 * fg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
+    }
+    const half_t* R = p.R ? p.R + zR : nullptr;
+    half_t* D = p.D + zD;
+    const bool rvec_ok = R && (p.ldr & 7) == 0;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        half8 rr[NI];
+        if (R) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
+                const int m = min(m0 + wr * 64 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
+                if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
+                else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
+            }
+        }
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq) {
+            const int mt = ms * 2 + mq;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                floatx4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
+                *(floatx4*)(wlds + (mq * 16 + fr) * PITCH + (nt * 16 + 4 * fg) * 4) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
+            const int m = m0 + wr * 64 + ms * 32 + row, n = n0 + wc * WN + ch * 8;
+            const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
+            const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            half8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)(R ? f[e] + (float)rr[i][e] : f[e]);
+            if (m < p.M && n < p.N) {
+                if (vec_ok && n + 8 <= p.N) *(half8*)(D + (long long)m * p.ldd + n) = v;
+                else for (int e = 0; e < 8 && n + e < p.N; ++e) D[(long long)m * p.ldd + n + e] = v[e];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+bool gemm_big_supported(const GemmArgs& a);   // gemm_big.hip: shared operand rules
+
+bool gemm_mid_supported(const GemmArgs& a)
+{
+    if (a.epi != EPI_STD || a.Npad % BN || (a.N & 7)) return false;
+    GemmArgs c = a;
+    c.Npad = 320 * ((a.Npad + 319) / 320);   // reuse the operand / offset-range rules, not the tile-width rule
+    return gemm_big_supported(c);
+}
+
+template <bool CONV, bool UPS>
+static void launch_mid_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
+{
+    static bool attr_set = false;
+    auto kern = gemm_mid_kernel<CONV, UPS>;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+}
+
+void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)
+{
+    p.nbm = cdiv(p.M, BM);
+    p.nbn = p.Npad / BN;
+    dim3 grid(p.nbm * p.nbn, p.splitk, batch);
+    if (conv && p.ups) launch_mid_t<true, true>(ctx, p, grid);
+    else if (conv)     launch_mid_t<true, false>(ctx, p, grid);
+    else               launch_mid_t<false, false>(ctx, p, grid);
+}

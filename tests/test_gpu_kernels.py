@@ -105,6 +105,38 @@ def test_conv_big_tile_kernel(engine, case):
     assert rel_l2(big, ref) < 2e-3
 
 
+MID_CASES = [
+    # NB, H, W, Cin, Cout, k, stride, ups -- shapes the 8-wave 256x160 kernel accepts (Cout % 160 == 0, Cin % 64 == 0)
+    (1, 32, 32, 320, 320, 3, 1, 0),     # 1024 rows: 4 row tiles x 2 column tiles, 45 K-tiles (3-deep ring wraps many times)
+    (2, 16, 16, 128, 640, 3, 1, 0),
+    (1, 24, 20, 64, 160, 3, 1, 0),      # ragged M tile (480 rows), 9 K-tiles
+    (1, 16, 16, 192, 320, 3, 2, 0),     # stride 2
+    (1, 12, 12, 128, 480, 3, 1, 1),     # fused nearest-2x upsample, three column tiles
+    (1, 30, 30, 256, 320, 1, 1, 0),     # linear, ragged M, 4 K-tiles
+    (1, 8, 8, 1280, 640, 3, 1, 0),      # long K: split-K slabs through this kernel
+    (1, 40, 40, 64, 160, 1, 1, 0),      # a single K-tile (prologue only)
+    (1, 20, 20, 128, 320, 1, 1, 0),     # two K-tiles (prologue covers everything, loop issues nothing)
+    (1, 20, 20, 192, 320, 1, 1, 0),     # three K-tiles (first use of the third ring slot)
+]
+
+
+@pytest.mark.parametrize("case", MID_CASES)
+def test_conv_mid_tile_kernel(engine, case):
+    NB, H, W, Cin, Cout, k, stride, ups = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    mid = run_conv(engine, 3, x, w, b, k, stride, ups)
+    xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
+    if ups:
+        xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=stride if k == 3 else 1,
+                   padding=1 if k == 3 else 0).permute(0, 2, 3, 1).numpy()
+    assert mid.shape == ref.shape
+    assert rel_l2(mid, ref) < 2e-3
+
+
 def run_attn(engine, naive, q, k, v, heads):
     from diffusers_amd import _lib
     NB, Sq, Cc = q.shape
