@@ -397,9 +397,10 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             launch_gemm_mid(ctx, p, a.batch, a.taps == 9);
 #ifdef SDE_DIAG
             if (p.stamps) {
-                unsigned h[65];
+                unsigned h[67];
                 HIP_CHECK(hipStreamSynchronize(ctx.stream));
                 HIP_CHECK(hipMemcpy(h, p.stamps, sizeof(h), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[stamps] loop: %u shader cycles in %u x 10 ns = %.3f GHz, %.1f cycles per K-tile\n", h[65], h[66], h[65] / (h[66] * 10.0), (double)h[65] / h[64]);
                 fprintf(stderr, "[stamps] M=%d N=%d K=%d: cycles per K-tile and wave: L0 | wait B | M0 | wait B | L1(+vmcnt g1) | wait B | M1(+vmcnt g0) | wait B\n", a.M, a.N, a.K);
                 for (int w = 0; w < 8; ++w) {
                     fprintf(stderr, "  wave %d:", w);

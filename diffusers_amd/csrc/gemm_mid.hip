@@ -26,10 +26,27 @@ constexpr unsigned OOB = 0x80000000u;
 constexpr int RSRC_FLAGS = 0x00020000;
 }  // namespace
 
+// Issue schedule: how many of a wave's staging parts go into each section {L0, M0, L1, M1} of a K-tile, for waves 0-3 (7 parts)
+// and waves 4-7 (6 parts).  Parts issued in an M section are spread among its 20 MFMAs.  Legal: waves 0-3 at most 2 parts in L0
+// (see the header), every part issued before the wave's counted wait of the NEXT tile.  Entry 0 is the product schedule.
+namespace {
+constexpr int kMidSched[4][2][4] = {
+    {{2, 1, 4, 0}, {3, 0, 3, 0}},
+    {{2, 2, 2, 1}, {2, 1, 2, 1}},
+    {{0, 4, 0, 3}, {0, 3, 0, 3}},
+    {{1, 2, 2, 2}, {1, 2, 1, 2}},
+};
+constexpr int sched_base(int v, int g, int sec) { int b = 0; for (int i = 0; i < sec; ++i) b += kMidSched[v][g][i]; return b; }
+constexpr int sched_slot(int k, int n) { return (k + 1) * 20 / (n + 1) - 1; }   // MFMA index after which part k of n is issued
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+}  // namespace
+
 // staging parts of one K-tile: 0-3 = A rows 64j..64j+63, 4-5 = W rows 0-63 / 64-127, 6 = W rows 128-159 (waves 0-3 only)
-template <bool CONV, bool UPS>
+template <bool CONV, bool UPS, int VAR>
 __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
 {
+    static_assert(kMidSched[VAR][0][0] <= 2, "waves 0-3 may stage only their own A rows in L0");
+    static_assert(sched_base(VAR, 0, 4) == 7 && sched_base(VAR, 1, 4) == 6, "every part exactly once");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -148,16 +165,12 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
     half8 bf[NT], af[MT];
 
     // waves 0-3 have 7 loads per K-tile in flight, waves 4-7 have 6: the counted wait leaves exactly the newest tile's
-#define WAIT_OLDER()                                                                         \
-    do {                                                                                      \
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");                        \
-        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");                                 \
-    } while (0)
+#define WAIT_PROLOGUE() do { if (grp == 0) wait_vmcnt<7>(); else wait_vmcnt<6>(); } while (0)
 
     // ---- prologue: K-tiles 0 and 1 into buffers 0 and 1
     issue_all(0);
     stage_advance();
-    if (nk > 1) { issue_all(1); stage_advance(); WAIT_OLDER(); }
+    if (nk > 1) { issue_all(1); stage_advance(); WAIT_PROLOGUE(); }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
@@ -165,19 +178,34 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
 #define LOAD_FRAGS(bo, ao)                                                                            \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(cur + (bo) + nt * 2048);  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = *(const half8*)(cur + (ao) + mt * 2048);
-#define MFMA_BLOCK()                                                                                  \
+#define ISSUE_L(sec)                                                                                  \
+    if (more2) {                                                                                      \
+        _Pragma("unroll") for (int i = 0; i < kMidSched[VAR][0][sec]; ++i) if (grp == 0) issue(sched_base(VAR, 0, sec) + i, nb_); \
+        _Pragma("unroll") for (int i = 0; i < kMidSched[VAR][1][sec]; ++i) if (grp == 1) issue(sched_base(VAR, 1, sec) + i, nb_); \
+    }
+#define MFMA_BLOCK(sec)                                                                               \
     __builtin_amdgcn_s_setprio(1);                                                                    \
-    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
-        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[nt][mt], 0, 0, 0); \
+    _Pragma("unroll") for (int i = 0; i < NT * MT; ++i) {                                              \
+        acc[i / MT][i % MT] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[i / MT], af[i % MT], acc[i / MT][i % MT], 0, 0, 0); \
+        _Pragma("unroll") for (int k = 0; k < kMidSched[VAR][0][sec]; ++k)                             \
+            if (i == sched_slot(k, kMidSched[VAR][0][sec])) { FENCE(); if (more2 && grp == 0) issue(sched_base(VAR, 0, sec) + k, nb_); FENCE(); } \
+        _Pragma("unroll") for (int k = 0; k < kMidSched[VAR][1][sec]; ++k)                             \
+            if (i == sched_slot(k, kMidSched[VAR][1][sec])) { FENCE(); if (more2 && grp == 1) issue(sched_base(VAR, 1, sec) + k, nb_); FENCE(); } \
+    }                                                                                                 \
     __builtin_amdgcn_s_setprio(0);
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 
 #ifdef SDE_DIAG
-    // in-kernel stamps (diagnostic build only): cycles per wave spent in each section of the two phases, summed over K-tiles
+    // in-kernel stamps (diagnostic build only).  -DSDE_DIAG=1: cycles per wave spent in each section of the two phases, summed
+    // over K-tiles.  -DSDE_DIAG=2: only one pair of stamps around the loop (shader clock = d(memtime) / d(memrealtime) * 100 MHz).
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+    const unsigned long long st_t0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
     unsigned st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#if SDE_DIAG == 1
 #define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[i] += (unsigned)(t_ - st_prev); st_prev = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 #else
 #define STAMP(i) do { } while (0)
 #endif
@@ -188,27 +216,21 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
         const bool more2 = kt + 2 < nk;
         // phase 0 (k-half 0).  Load section L0: waves 0-3 may only overwrite rows nobody else reads (A rows 0-127).
         LOAD_FRAGS(b_rd0, a_rd0)
-        if (more2) {
-            if (grp == 0) { issue(0, nb_); issue(1, nb_); }
-            else { issue(0, nb_); issue(1, nb_); issue(2, nb_); }
-        }
+        ISSUE_L(0)
         FENCE(); STAMP(0); __builtin_amdgcn_s_barrier(); STAMP(1); FENCE();
-        if (more2 && grp == 0) issue(6, nb_);
-        MFMA_BLOCK()
+        MFMA_BLOCK(1)
         FENCE(); STAMP(2); __builtin_amdgcn_s_barrier(); STAMP(3); FENCE();
         // phase 1 (k-half 1)
         LOAD_FRAGS(b_rd1, a_rd1)
-        if (more2) {
-            if (grp == 0) { issue(2, nb_); issue(3, nb_); issue(4, nb_); issue(5, nb_); }
-            else { issue(3, nb_); issue(4, nb_); issue(5, nb_); }
-        }
+        ISSUE_L(2)
         FENCE();
-        if (grp == 1) { if (more2) WAIT_OLDER(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }   // tile kt+1 landed
+        // counted waits leave exactly what the wave has issued of tile kt+2 so far in flight: tile kt+1 has landed
+        if (grp == 1) { if (more2) wait_vmcnt<sched_base(VAR, 1, 3)>(); else wait_vmcnt<0>(); }
         STAMP(4); __builtin_amdgcn_s_barrier(); STAMP(5); FENCE();
-        if (more2) stage_advance();   // scalar work of the next tile's addresses rides under the MFMAs
-        MFMA_BLOCK()
+        MFMA_BLOCK(3)
+        if (more2) stage_advance();   // scalar work of the next tile's addresses, under the tail of the MFMAs
         FENCE();
-        if (grp == 0) { if (more2) WAIT_OLDER(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        if (grp == 0) { if (more2) wait_vmcnt<7>(); else wait_vmcnt<0>(); }
         STAMP(6); __builtin_amdgcn_s_barrier(); STAMP(7); FENCE();
         cb = cb == 2 ? 0 : cb + 1;
     }
@@ -217,14 +239,19 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
     if (p.stamps && blockIdx.x == 8 && lane == 0) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) p.stamps[wid * 8 + i] = st_sum[i];
-        if (wid == 0) p.stamps[64] = nk;
+        if (wid == 0) {
+            p.stamps[64] = nk;
+            p.stamps[65] = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0);
+            p.stamps[66] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+        }
     }
 #endif
 #undef STAMP
 #undef LOAD_FRAGS
 #undef MFMA_BLOCK
 #undef FENCE
-#undef WAIT_OLDER
+#undef WAIT_PROLOGUE
+#undef ISSUE_L
 
     // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
     const long long zD = z * p.sD, zR = z * p.sR;
@@ -312,11 +339,11 @@ bool gemm_mid_supported(const GemmArgs& a)
     return gemm_big_supported(c);
 }
 
-template <bool CONV, bool UPS>
+template <bool CONV, bool UPS, int VAR = 0>
 static void launch_mid_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
     static bool attr_set = false;
-    auto kern = gemm_mid_kernel<CONV, UPS>;
+    auto kern = gemm_mid_kernel<CONV, UPS, VAR>;
     if (!attr_set) {
         HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         attr_set = true;
@@ -329,6 +356,13 @@ void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)
     p.nbm = cdiv(p.M, BM);
     p.nbn = p.Npad / BN;
     dim3 grid(p.nbm * p.nbn, p.splitk, batch);
+#ifdef SDE_DIAG
+    // schedule experiments (diagnostic builds): SDE_MIDVAR=1..3 selects kMidSched[v] for plain 3x3 convs
+    static const int var = getenv("SDE_MIDVAR") ? atoi(getenv("SDE_MIDVAR")) : 0;
+    if (conv && !p.ups && var == 1) return launch_mid_t<true, false, 1>(ctx, p, grid);
+    if (conv && !p.ups && var == 2) return launch_mid_t<true, false, 2>(ctx, p, grid);
+    if (conv && !p.ups && var == 3) return launch_mid_t<true, false, 3>(ctx, p, grid);
+#endif
     if (conv && p.ups) launch_mid_t<true, true>(ctx, p, grid);
     else if (conv)     launch_mid_t<true, false>(ctx, p, grid);
     else               launch_mid_t<false, false>(ctx, p, grid);
