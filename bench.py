@@ -85,16 +85,28 @@ def main():
     ap.add_argument("--model-dir", default=os.environ.get("SDE_BENCH_MODEL_DIR", "/tmp/sde_bench_sd15_f16"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--cfg-pair-split", action="store_true",
+                    help="BASELINE config 3 variant: ranks (2p, 2p+1) share 2*batch prompts; each runs one CFG half of every UNet "
+                         "call (UNet batch stays 2*batch per GPU) and they all-gather the halves over RCCL once per step")
     args = ap.parse_args()
 
+    if os.environ.get("SDE_BENCH_DEBUG"):      # dump every thread's Python stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SDE_BENCH_DEBUG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist
+        # SDE_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then share devices)
+        backend = os.environ.get("SDE_BENCH_BACKEND", "nccl")
+        local_rank %= max(1, torch.cuda.device_count())
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
@@ -111,7 +123,15 @@ def main():
     pipe = StableDiffusionPipeline(model_dir, StableDiffusionOptions(device_id=local_rank))
     load_s = time.time() - t0
     B, S, D, H, W = args.batch, 77, 768, 512, 512
-    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    pair = None
+    if args.cfg_pair_split:
+        from diffusers_amd.sharding import CfgPair, pair_layout
+        assert dist is not None, "--cfg-pair-split needs an even number of ranks >= 2"
+        pidx, half, n_pairs = pair_layout(world, rank)
+        groups = [dist.new_group([2 * p, 2 * p + 1]) for p in range(n_pairs)]
+        pair = CfgPair(dist, groups[pidx], half, dev)
+        B = 2 * B                                      # prompts per PAIR; each GPU still runs a UNet batch of 2*args.batch
+    g = torch.Generator(device="cpu").manual_seed(1 + (rank // 2 if pair else rank))   # identical inputs inside a pair
     ehs = (torch.randn(2 * B, S, D, generator=g) * 0.5).to(dev)
     init = torch.randn(B, 4, H // 8, W // 8, generator=g).to(dev)
     images = torch.empty(B, H, W, 3, device=dev, dtype=torch.float32)
@@ -120,7 +140,7 @@ def main():
 
     def one_step():
         sch = N.BY_NAME[args.scheduler].stable_diffusion_v1_optimized_default()
-        return opts.run(pipe, sch, device_ptrs=ptrs)
+        return opts.run(pipe, sch, device_ptrs=ptrs, cfg_pair=pair)
 
     for _ in range(args.warmup):
         one_step()
@@ -134,14 +154,17 @@ def main():
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.isfinite(images).all(), "non-finite pixels in the decoded images"
+    mine = images if pair is None else (images[:(B + 1) // 2] if pair.half == 0 else images[(B + 1) // 2:])
+    assert torch.isfinite(mine).all(), "non-finite pixels in the decoded images"
 
     # per-kernel timing: same workload once more with HIP events around every launch (on the engine's stream)
     roof = None
     kernel_table = []
+    if pair is not None and rank != 0:
+        one_step()                      # the pair's peer (and every other pair, to keep ranks aligned) takes part in the profiled pass
     if rank == 0:
         pipe.profile_reset(); pipe.profile(True)
         rp = one_step()
@@ -177,16 +200,18 @@ def main():
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "launches": dom["launches"],
                     "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2)}
 
-    total_images = world * B * args.steps
+    total_images = (world // 2 if pair else world) * B * args.steps
     value = total_images / elapsed
     per_image_tflop = (2 * args.denoise_steps * UNET_GFLOP_PER_SAMPLE + VAE_GFLOP_PER_IMAGE) / 1e3
     out = {
         "metric": "images/sec (SD1.5 512x512, 30 steps, fp16)", "value": round(value, 4), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"SD v1.5 geometry 512x512, {args.scheduler} {args.denoise_steps} steps, CFG 7.5, batch {B} per GPU "
-                               f"(UNet batch {2 * B}), fp16, + batched VAE decode; random-init weights, text length 77",
-                   "global_batch": world * B, "parallelism": f"dp{world} (independent prompts, no collective)",
+        "config": {"workload": f"SD v1.5 geometry 512x512, {args.scheduler} {args.denoise_steps} steps, CFG 7.5, batch {args.batch} per GPU "
+                               f"(UNet batch {2 * args.batch}), fp16, + batched VAE decode; random-init weights, text length 77",
+                   "global_batch": (world // 2 if pair else world) * B,
+                   "parallelism": (f"dp{world // 2} x cfg-pair2 (uncond/text halves on paired GPUs, 2-rank RCCL all-gather of [B,4,h,w] per step)"
+                                   if pair else f"dp{world} (independent prompts, no collective)"),
                    "unet_calls_per_step": calls // max(1, args.steps), "reference_quirks": True},
         "unet_it_per_s": round(calls / (unet_ms * 1e-3), 3) if unet_ms else None,
         "unet_ms_per_call": round(unet_ms / max(1, calls), 3), "vae_ms_per_batch": round(vae_ms / args.steps, 2),

@@ -36,6 +36,7 @@ class SchedCfg(C.Structure):
 
 
 CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_float, c_float_p, C.c_size_t, C.c_void_p)
+EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)   # sde_exchange_fn
 
 
 class Txt2ImgOpts(C.Structure):
@@ -45,7 +46,8 @@ class Txt2ImgOpts(C.Structure):
                 ("init_latents", C.c_void_p), ("step_noise", C.c_void_p), ("buffers_on_device", C.c_int),
                 ("skip_decode", C.c_int), ("callback_kind", C.c_int), ("callback_frequency", C.c_int),
                 ("callback", CALLBACK), ("callback_user", C.c_void_p), ("noise_pred_out", C.c_void_p),
-                ("latents_out", C.c_void_p), ("final_latents_out", C.c_void_p)]
+                ("latents_out", C.c_void_p), ("final_latents_out", C.c_void_p),
+                ("cfg_half", C.c_int), ("exchange", EXCHANGE), ("exchange_user", C.c_void_p)]
 
 
 class RunStats(C.Structure):

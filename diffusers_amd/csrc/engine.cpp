@@ -578,6 +578,12 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         const int B = o->batch_size, h = o->height / 8, w = o->width / 8, S = o->S, D = o->D, C = e->unet.in_channels;
         const bool cfg = o->guidance_scale > 1.0f;  // :258
         const int N = cfg ? 2 * B : B;
+        // CFG-pair split: this engine runs one half of the CFG batch; the peer's half arrives through the exchange hook
+        const int half = o->cfg_half;
+        SDE_REQUIRE(half >= 0 && half <= 2, SDE_ERR_INVALID_ARGUMENT, "cfg_half must be 0, 1 or 2");
+        SDE_REQUIRE(!half || (cfg && o->exchange), SDE_ERR_INVALID_ARGUMENT, "cfg_half needs guidance_scale > 1 and an exchange hook");
+        const int Nu = half ? B : N;                 // UNet batch on this engine
+        const size_t half_off = half == 2 ? 1 : 0;   // which half of [2B] this engine owns
         const size_t per = (size_t)B * C * h * w;
         const int Cp = UNetModel::kInPad;
         hipStream_t st = e->stream;
@@ -598,7 +604,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         e->x_packed.ensure((size_t)N * h * w * Cp * sizeof(half_t));
         HIP_CHECK(hipMemsetAsync(e->x_packed.p, 0, (size_t)N * h * w * Cp * sizeof(half_t), st));
         e->ehs_h.ensure((size_t)N * S * D * sizeof(half_t));
-        setup_kv(e, N, S);
+        setup_kv(e, Nu, S);
         float* d_lat = e->latents.as<float>();
         std::vector<float> host_tmp;
         if (o->buffers_on_device) {
@@ -630,14 +636,20 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         // first model input: scale_model_input(concat(latents, latents), t0)  (:273-278)
         {
             float div = sch->input_scale_divisor(ts[0]);
-            launch_pack_latents(e->ctx, d_lat, e->x_packed.as<half_t>(), B, cfg ? 2 : 1, C, h, w, Cp, 1.0f / div);
+            launch_pack_latents(e->ctx, d_lat, e->x_packed.as<half_t>(), B, (cfg && !half) ? 2 : 1, C, h, w, Cp, 1.0f / div);
         }
         int unet_calls = 0;
         std::vector<float> cb_buf;
         for (int i = 0; i < nt; ++i) {
             const float t = ts[(size_t)i];
-            unet_run(e, e->x_packed.as<half_t>(), N, h, w, t, e->ehs_h.as<half_t>(), S, i == 0, e->model_out.as<float>());  // :283
+            unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, e->ehs_h.as<half_t>() + half_off * B * S * D, S, i == 0,
+                     e->model_out.as<float>() + half_off * per);                                             // :283
             ++unet_calls;
+            if (half) {
+                HIP_CHECK(hipStreamSynchronize(st));
+                SDE_REQUIRE(o->exchange(e->model_out.as<float>(), per, (int)half_off, o->exchange_user) != 0, SDE_ERR_EXCHANGE,
+                            "CFG-pair exchange hook failed at step " + std::to_string(i));
+            }
             StepPlan p;
             sch->plan(t, p);
             StepArgs a;
@@ -713,14 +725,21 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         if (o->final_latents_out) HIP_CHECK(hipMemcpyAsync(o->final_latents_out, d_lat, per * 4, hipMemcpyDeviceToHost, st));
         if (!o->skip_decode) {                                                                           // :326
             const int up = e->vae.upscale();  // 8 for Stable Diffusion VAEs => [B,H,W,3]
-            const size_t no = (size_t)B * h * up * w * up * e->vae.out_channels;
-            if (o->buffers_on_device) decode_dev(e, d_lat, B, h, w, EPI_IMAGE, images_out);
-            else {
-                e->images.ensure(no * 4);
-                decode_dev(e, d_lat, B, h, w, EPI_IMAGE, e->images.as<float>());
+            const size_t img = (size_t)h * up * w * up * e->vae.out_channels;
+            // CFG-pair split: both engines hold the same latents; each decodes its share of the batch (rows [b0, b0+nb))
+            const int B0 = (B + 1) / 2;
+            const int b0 = half == 2 ? B0 : 0, nb = half == 0 ? B : (half == 1 ? B0 : B - B0);
+            const size_t no = (size_t)nb * img;
+            if (nb > 0) {
+                if (o->buffers_on_device) decode_dev(e, d_lat + (size_t)b0 * C * h * w, nb, h, w, EPI_IMAGE, images_out + (size_t)b0 * img);
+                else {
+                    e->images.ensure(no * 4);
+                    decode_dev(e, d_lat + (size_t)b0 * C * h * w, nb, h, w, EPI_IMAGE, e->images.as<float>());
+                }
             }
             HIP_CHECK(hipEventRecord(ev2, st));
-            if (!o->buffers_on_device) HIP_CHECK(hipMemcpyAsync(images_out, e->images.p, no * 4, hipMemcpyDeviceToHost, st));
+            if (!o->buffers_on_device && nb > 0)
+                HIP_CHECK(hipMemcpyAsync(images_out + (size_t)b0 * img, e->images.p, no * 4, hipMemcpyDeviceToHost, st));
         } else HIP_CHECK(hipEventRecord(ev2, st));
         HIP_CHECK(hipStreamSynchronize(st));
         if (stats) {

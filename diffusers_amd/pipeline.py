@@ -206,9 +206,10 @@ class StableDiffusionTxt2ImgOptions:
         return self
 
     def run(self, session: StableDiffusionPipeline, scheduler: DiffusionScheduler, *, trace: bool = False,
-            skip_decode: bool = False, device_ptrs: Optional[dict] = None) -> Txt2ImgResult:
+            skip_decode: bool = False, device_ptrs: Optional[dict] = None, cfg_pair=None) -> Txt2ImgResult:
         """impl_txt2img.rs:246-327.  ``device_ptrs`` (bench path) = dict(ehs=, init_latents=, step_noise=, images=)
-        of raw device addresses; then nothing crosses PCIe inside the call."""
+        of raw device addresses; then nothing crosses PCIe inside the call.  ``cfg_pair`` (sharding.CfgPair): this
+        process runs one half of the CFG batch and swaps halves with its peer once per step."""
         L = _lib.lib()
         o = _lib.Txt2ImgOpts()
         L.sde_txt2img_opts_default(C.byref(o))
@@ -282,8 +283,27 @@ class StableDiffusionTxt2ImgOptions:
             res.final_latents = np.zeros((B, 4, h, w), np.float32)
             o.noise_pred_out, o.latents_out, o.final_latents_out = (res.noise_pred.ctypes.data, res.latents.ctypes.data,
                                                                     res.final_latents.ctypes.data)
+        if cfg_pair is not None:
+            pair_errors = []
+
+            def xchg(ptr, half_elems, my_half, _user):
+                try:
+                    cfg_pair.exchange(ptr, half_elems, my_half)
+                    return 1
+                except Exception as exc:  # never let an exception cross the C boundary
+                    pair_errors.append(exc)
+                    return 0
+
+            xfn = _lib.EXCHANGE(xchg)
+            keep.append(xfn)
+            o.cfg_half, o.exchange = cfg_pair.half + 1, xfn
         st = _lib.RunStats()
-        _lib.check(L.sde_txt2img_run(session._h, scheduler._h, C.byref(o), images_ptr, C.byref(st)))
+        try:
+            _lib.check(L.sde_txt2img_run(session._h, scheduler._h, C.byref(o), images_ptr, C.byref(st)))
+        except _lib.SdeError as err:
+            if cfg_pair is not None and pair_errors:
+                raise pair_errors[0] from err
+            raise
         res.unet_calls, res.total_ms, res.unet_ms, res.vae_ms = st.unet_calls, st.total_ms, st.unet_ms, st.vae_ms
         if trace and res.noise_pred is not None:
             res.noise_pred = res.noise_pred[:st.unet_calls]

@@ -1,6 +1,11 @@
 """Multi-GPU partitioning of the txt2img path: independent prompts shard contiguously over ranks,
 one process per GPU, weights replicated, NO data-path collective.  torch.distributed is only used to line ranks up
-(barrier) and to take the max elapsed time for whole-job throughput."""
+(barrier) and to take the max elapsed time for whole-job throughput.
+
+Optional CFG-pair split (BASELINE config 3): GPUs are paired (ranks 2p, 2p+1 — xGMI neighbours); the even rank runs the
+unconditional half of every UNet call, the odd rank the text half, and the two swap their [B,4,h,w] outputs once per
+step with a 2-rank all-gather (RCCL over xGMI when the backend is nccl).  It halves per-image LATENCY when there are
+fewer prompts than GPUs; for throughput plain prompt sharding is better (no exchange at all)."""
 from __future__ import annotations
 
 from typing import Tuple
@@ -30,3 +35,63 @@ def job_throughput(dist, local_units: int, local_elapsed_s: float, device=None) 
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(u.item() / t.item())
+
+
+def pair_layout(world: int, rank: int) -> Tuple[int, int, int]:
+    """CFG-pair split: returns (pair_index, half, n_pairs); half 0 = unconditional (even rank), 1 = text (odd rank).
+    Prompts are then sharded over PAIRS: ``shard_range(total, n_pairs, pair_index)``."""
+    if world <= 0 or world % 2 or not (0 <= rank < world):
+        raise ValueError("the CFG-pair split needs an even number of ranks")
+    return rank // 2, rank % 2, world // 2
+
+
+class _DevicePtr:
+    """Exposes a raw device address as __cuda_array_interface__ so torch can wrap it without a copy."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (int(ptr), False), "version": 2}
+
+
+class CfgPair:
+    """Exchange object handed to ``StableDiffusionTxt2ImgOptions.run(cfg_pair=...)``.
+
+    ``half``: 0 = this process computes the unconditional half, 1 = the text half.
+    ``group``: a torch.distributed group holding exactly the two peers, the unconditional rank FIRST.
+    With the nccl backend (RCCL) the all-gather runs device-to-device over xGMI; with gloo (CPU tests, or two ranks
+    sharing one GPU) the halves are staged through host memory."""
+
+    def __init__(self, dist, group, half: int, device=None):
+        if half not in (0, 1):
+            raise ValueError("half must be 0 or 1")
+        self.dist, self.group, self.half, self.device = dist, group, half, device
+        self.backend = dist.get_backend(group) if dist is not None else None
+        if dist is not None and dist.get_world_size(group) != 2:
+            raise ValueError("a CFG pair is a group of exactly two ranks")
+        if dist is not None and dist.get_rank(group) != half:
+            raise ValueError("group order must be (unconditional rank, text rank)")
+
+    def gather(self, full):
+        """``full``: tensor [2, n] (device or CPU) whose row ``self.half`` is filled; fills the other row."""
+        import torch
+        mine = full[self.half].contiguous()
+        if self.backend == "nccl":
+            out = torch.empty_like(full)
+            self.dist.all_gather_into_tensor(out.view(-1), mine.view(-1), group=self.group)
+            full[1 - self.half].copy_(out[1 - self.half])
+        else:
+            host = mine.detach().to("cpu")
+            parts = [torch.empty_like(host), torch.empty_like(host)]
+            self.dist.all_gather(parts, host, group=self.group)
+            full[1 - self.half].copy_(parts[1 - self.half])
+        return full
+
+    def exchange(self, ptr: int, half_elems: int, my_half: int):
+        """The engine's sde_exchange_fn: ``ptr`` = device f32 [2][half_elems], engine stream idle on entry; returns
+        after the peer's half is in place."""
+        import torch
+        if my_half != self.half:
+            raise RuntimeError(f"engine runs half {my_half}, pair object was built for half {self.half}")
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        full = torch.as_tensor(_DevicePtr(ptr, 2 * half_elems), device=dev).view(2, half_elems)
+        self.gather(full)
+        torch.cuda.current_stream(dev).synchronize()

@@ -28,7 +28,8 @@ typedef enum sde_status {
     SDE_ERR_MODEL = 4,            /* ONNX parse / weight-binding failure */
     SDE_ERR_DEVICE = 5,           /* HIP runtime error, no GPU, extension built for another arch */
     SDE_ERR_SCHEDULER = 6,        /* scheduler misuse that panics in the reference (euler_discrete.rs:140,181) */
-    SDE_ERR_CANCELLED = 7         /* a callback returned 0 (reference: `break`, impl_txt2img.rs:319-321) */
+    SDE_ERR_CANCELLED = 7,        /* a callback returned 0 (reference: `break`, impl_txt2img.rs:319-321) */
+    SDE_ERR_EXCHANGE = 8          /* the CFG-pair exchange hook reported a failure (no counterpart in the reference) */
 } sde_status;
 
 typedef struct sde_engine sde_engine;
@@ -151,6 +152,14 @@ typedef enum sde_callback_kind {  /* StableDiffusionCallback, pipelines/stable_d
  * payload element count, user pointer.  Return 0 to stop the loop (reference: `false` -> break). */
 typedef int (*sde_callback_fn)(int step, float timestep, const float* payload, size_t payload_len, void* user);
 
+/* CFG-pair split (BASELINE config 3): two engines on two GPUs each run ONE half of the classifier-free-guidance
+ * batch (impl_txt2img.rs:273-301 computes both in one session.run) and swap the halves once per step.  The engine calls this
+ * hook on the calling thread after its UNet call, with its stream idle: `d_model_out` is the DEVICE buffer f32 [2][B,4,h,w]
+ * (uncond half first); half `my_half` (0 or 1) is filled.  The hook fills the other half with the peer's output (e.g. a
+ * 2-rank RCCL all-gather over xGMI) and returns non-zero once that transfer has completed; 0 aborts the run.
+ * No counterpart in the reference (single ORT session). */
+typedef int (*sde_exchange_fn)(float* d_model_out, size_t half_elems, int my_half, void* user);
+
 typedef struct sde_txt2img_opts {
     int height, width;          /* must be divisible by 8 (impl_txt2img.rs:251-253) */
     float guidance_scale;       /* CFG is on iff > 1.0 (:258) */
@@ -169,6 +178,12 @@ typedef struct sde_txt2img_opts {
     float* noise_pred_out;      /* f32 [n_timesteps,B,4,h,w]: CFG-combined model output per step */
     float* latents_out;         /* f32 [n_timesteps,B,4,h,w]: latents after each scheduler step */
     float* final_latents_out;   /* f32 [B,4,h,w] */
+    /* CFG-pair split: 0 = both halves on this engine (default); 1 = this engine runs the unconditional half, 2 = the text
+     * half (UNet batch B instead of 2B).  `ehs` stays [2B,S,D]; seeds / init_latents / step_noise must be identical on both
+     * engines (the scheduler step is replicated, so both end with the same latents).  Needs guidance_scale > 1.
+     * Each engine decodes its share of the batch: rows [0, ceil(B/2)) of images_out on the unconditional engine, rows
+     * [ceil(B/2), B) on the text engine; the other rows are left untouched. */
+    int cfg_half; sde_exchange_fn exchange; void* exchange_user;
 } sde_txt2img_opts;
 
 void sde_txt2img_opts_default(sde_txt2img_opts* o);

@@ -172,3 +172,69 @@ def test_seeded_runs_are_reproducible(pipe):
         return StableDiffusionTxt2ImgOptions(height=128, width=128, text_embeddings=ehs, batch_size=1, steps=4, seed=seed).run(pipe, sch, trace=True).final_latents
     a, b, c = go(5), go(5), go(6)
     assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+@pytest.mark.parametrize("kind,rescale", [("euler_a", None), ("dpmpp", 0.7)])
+def test_cfg_pair_split_matches_single_engine(tiny_model_dir, pipe, kind, rescale):
+    """SURVEY 8e / BASELINE config 3: two engines each run one half of the CFG batch and swap halves once per step through
+    the sde_exchange_fn hook.  Here the two 'ranks' are two threads with two engines on the one GPU and the exchange is
+    a device-to-device copy between them (tests/test_sharding_gloo.py covers the torch.distributed transport); the
+    result must match the single-engine run, whose UNet sees both halves in one batch."""
+    import threading
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionPipeline, StableDiffusionTxt2ImgOptions
+    from diffusers_amd.sharding import CfgPair
+
+    class ThreadPair(CfgPair):
+        slots = [None, None]
+        barrier = threading.Barrier(2)
+
+        def __init__(self, half):
+            super().__init__(None, None, half)
+
+        def gather(self, full):
+            ThreadPair.slots[self.half] = full[self.half].clone()
+            torch.cuda.synchronize()
+            ThreadPair.barrier.wait(timeout=60)
+            full[1 - self.half].copy_(ThreadPair.slots[1 - self.half])
+            torch.cuda.synchronize()
+            ThreadPair.barrier.wait(timeout=60)
+            return full
+
+    B, h, w, steps = 2, 16, 16, 5
+    rng = np.random.default_rng(23)
+    ehs = (rng.standard_normal((2 * B, 77, 64)) * 0.5).astype(np.float32)
+    init = rng.standard_normal((B, 4, h, w)).astype(np.float32)
+    noise = rng.standard_normal((steps + 2, B, 4, h, w)).astype(np.float32)
+    mk = lambda: StableDiffusionTxt2ImgOptions(height=h * 8, width=w * 8, guidance_scale=7.5, rescale_cfg=rescale, steps=steps,
+                                               text_embeddings=ehs, batch_size=B, init_latents=init, step_noise=noise)
+    whole = mk().run(pipe, N.BY_NAME[kind].stable_diffusion_v1_optimized_default(), trace=True)
+    peer = StableDiffusionPipeline(tiny_model_dir)
+    out, errs = [None, None], []
+
+    def rank(half, session):
+        try:
+            out[half] = mk().run(session, N.BY_NAME[kind].stable_diffusion_v1_optimized_default(), trace=True,
+                                 cfg_pair=ThreadPair(half))
+        except Exception as exc:
+            errs.append(exc)
+            ThreadPair.barrier.abort()
+
+    th = [threading.Thread(target=rank, args=(0, pipe)), threading.Thread(target=rank, args=(1, peer))]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    peer.close()
+    assert not errs, errs
+    assert out[0] is not None and out[1] is not None
+    assert np.array_equal(out[0].final_latents, out[1].final_latents)            # replicated scheduler step: identical
+    for i in range(whole.unet_calls):
+        assert rel_l2(out[0].noise_pred[i], whole.noise_pred[i]) < 2e-3, (kind, i)   # UNet batch B vs 2B: other tile shapes
+    B0 = (B + 1) // 2                                                             # each engine decodes its share
+    assert psnr(out[0].images[:B0], whole.images[:B0]) >= 45.0 and psnr(out[1].images[B0:], whole.images[B0:]) >= 45.0
+    # misuse: half without hook / without CFG
+    from diffusers_amd import _lib
+    o = mk()
+    o.guidance_scale = 1.0
+    o.text_embeddings = ehs[:B]
+    with pytest.raises(_lib.SdeError, match="cfg_half"):
+        o.run(pipe, N.BY_NAME[kind].stable_diffusion_v1_optimized_default(), cfg_pair=ThreadPair(0))
