@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
     constexpr int KROW = DQK + 8;        // padded K-tile row (elements)
     constexpr int VROW = DVT * 16 + 8;   // padded V-tile row (elements); row stride stays a multiple of 16 B
     constexpr int KS = DQK / 32;         // k-steps of the score product
-    __shared__ __attribute__((aligned(16))) half_t sK[64 * KROW];
-    __shared__ __attribute__((aligned(16))) half_t sV[64 * VROW];
+    constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
+    constexpr int NBUF = PREFETCH ? 2 : 1;  // prefetching variants double-buffer the tiles in LDS: one barrier per tile
+    __shared__ __attribute__((aligned(16))) half_t sK_[NBUF * 64 * KROW];
+    __shared__ __attribute__((aligned(16))) half_t sV_[NBUF * 64 * VROW];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -130,7 +132,9 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             vreg[i] = v;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](int buf) {
+        half_t* sK = sK_ + buf * 64 * KROW;
+        half_t* sV = sV_ + buf * 64 * VROW;
 #pragma unroll
         for (int i = 0; i < KN; ++i) if (kcol[i] >= 0) *(half8*)(sK + klds[i]) = kreg[i];
 #pragma unroll
@@ -138,22 +142,27 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
     };
     // pad columns (>= d) never change: written once.  ONES: the very last V column holds 1.0 (softmax denominator).
 #pragma unroll
-    for (int i = 0; i < KN; ++i)
-        if (kcol[i] < 0 && klds[i] >= 0) {
-            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (FOLD && klds[i] - krow[i] * KROW == d) { z[0] = (half_t)1.0f; z[1] = (half_t)1.0f; }   // the two max-carrying columns
-            *(half8*)(sK + klds[i]) = z;
-        }
+    for (int b = 0; b < NBUF; ++b) {
 #pragma unroll
-    for (int i = 0; i < VN; ++i)
-        if (vcol[i] < 0 && vlds[i] >= 0) {
-            half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (ONES && vlds[i] - vrow[i] * VROW == DVT * 16 - 8) z[7] = (half_t)1.0f;
-            *(half8*)(sV + vlds[i]) = z;
-        }
+        for (int i = 0; i < KN; ++i)
+            if (kcol[i] < 0 && klds[i] >= 0) {
+                half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (FOLD && klds[i] - krow[i] * KROW == d) { z[0] = (half_t)1.0f; z[1] = (half_t)1.0f; }   // the two max-carrying columns
+                *(half8*)(sK_ + b * 64 * KROW + klds[i]) = z;
+            }
+#pragma unroll
+        for (int i = 0; i < VN; ++i)
+            if (vcol[i] < 0 && vlds[i] >= 0) {
+                half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (ONES && vlds[i] - vrow[i] * VROW == DVT * 16 - 8) z[7] = (half_t)1.0f;
+                *(half8*)(sV_ + b * 64 * VROW + vlds[i]) = z;
+            }
+    }
 
-    auto tile = [&](int kv0, auto mask_tag) {
+    auto tile = [&](int kv0, int buf, auto mask_tag) {
         constexpr bool MASK = decltype(mask_tag)::value;
+        const half_t* sK = sK_ + buf * 64 * KROW;
+        const half_t* sV = sV_ + buf * 64 * VROW;
         // scores S^T[key][q]: s[kt][qt][r] <-> key = kv0 + 16*kt + 4*fg + r, q = q0 + 16*qt + fr
         floatx4 s[4][2];
 #pragma unroll
@@ -177,19 +186,21 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
                     for (int r = 0; r < 4; ++r)
                         if (kv0 + kt * 16 + fg * 4 + r >= p.Skv) s[kt][qt][r] = -INFINITY;
             }
+            // lane-local maximum of this lane's 16 scores of q-tile qt.  The query's other keys sit in the three lanes fr+16k;
+            // the cross-lane reduction (two LDS round trips) is only paid when some lane sees the deferred-rescale trigger.
             float mx = s[0][qt][0];
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16));
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
             // deferred rescale: raise the running max only when it grows by more than THR (log2 units)
             if (FOLD) {
                 // scores are already s*c - M_old (M_old = 0 before the first tile): mx is the growth of the maximum
                 const bool first = mrow[qt] == -INFINITY;
-                const bool grow = mx > ATTN_RESCALE_THR || first;
-                if (__any(grow)) {
+                if (__any(mx > ATTN_RESCALE_THR || first)) {
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const bool grow = mx > ATTN_RESCALE_THR || first;
                     const float delta = grow ? mx : 0.f;
                     const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
                     mrow[qt] = (first ? 0.f : mrow[qt]) + delta;
@@ -211,18 +222,20 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
                     }
                 }
             } else {
-            const bool grow = mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY;
-            if (__any(grow)) {
-                float mnew = grow ? mx : mrow[qt];
-                float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * csl);   // exp2(-inf) = 0 on the first tile
-                if (mrow[qt] == mnew) alpha = 1.0f;
-                mrow[qt] = mnew;
-                lrow[qt] *= alpha;
+                if (__any(mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY)) {
+                    mx = fmaxf(mx, __shfl_xor(mx, 16));
+                    mx = fmaxf(mx, __shfl_xor(mx, 32));
+                    const bool grow = mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY;
+                    float mnew = grow ? mx : mrow[qt];
+                    float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * csl);   // exp2(-inf) = 0 on the first tile
+                    if (mrow[qt] == mnew) alpha = 1.0f;
+                    mrow[qt] = mnew;
+                    lrow[qt] *= alpha;
 #pragma unroll
-                for (int dt = 0; dt < DVT; ++dt)
+                    for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
-            }
+                        for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+                }
             }
         }
         // phase 2 (straight line): V^T fragments, then exp / PV per q-tile so that the second tile's exponentials can
@@ -272,16 +285,29 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         }
     };
 
-    constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
-    if (PREFETCH) load_tile(0);
-    for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
-        if (!PREFETCH) load_tile(kv0);
-        __syncthreads();  // everyone done reading the previous tile
-        store_tile();
+    if (PREFETCH) {
+        // tile t is computed from LDS buffer t&1 while tile t+1 moves registers -> the other buffer and tile t+2 is in flight
+        load_tile(0);
+        store_tile(0);
+        if (64 < p.Skv) load_tile(64);
         __syncthreads();
-        if (PREFETCH && kv0 + 64 < p.Skv) load_tile(kv0 + 64);
-        if (kv0 + 64 > p.Skv) tile(kv0, std::true_type{});   // block-uniform branch
-        else tile(kv0, std::false_type{});
+        int buf = 0;
+        for (int kv0 = 0; kv0 < p.Skv; kv0 += 64, buf ^= 1) {
+            if (kv0 + 64 < p.Skv) store_tile(buf ^ 1);     // last read in the previous iteration, which ended with a barrier
+            if (kv0 + 128 < p.Skv) load_tile(kv0 + 128);
+            if (kv0 + 64 > p.Skv) tile(kv0, buf, std::true_type{});   // block-uniform branch
+            else tile(kv0, buf, std::false_type{});
+            __syncthreads();
+        }
+    } else {
+        for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
+            load_tile(kv0);
+            __syncthreads();  // everyone done reading the previous tile
+            store_tile(0);
+            __syncthreads();
+            if (kv0 + 64 > p.Skv) tile(kv0, 0, std::true_type{});   // block-uniform branch
+            else tile(kv0, 0, std::false_type{});
+        }
     }
     // finish: o[dt][qt][r] <-> d index 16*dt + 4*fg + r, q = q0 + 16*qt + fr
 #pragma unroll
