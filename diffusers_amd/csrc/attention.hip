@@ -118,7 +118,30 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         vrow[i] = r; vcol[i] = (idx < 64 * VCH && c < d) ? c : -1; vlds[i] = idx < 64 * VCH ? r * VROW + c : -1;
     }
     const int last_key = p.Skv - 1;
+    // byte offsets of this thread's chunks inside a full tile (uniform tile base + 32-bit offset: no per-tile address math)
+    unsigned koff[KN], voff[VN];
+#pragma unroll
+    for (int i = 0; i < KN; ++i) koff[i] = (unsigned)(krow[i] * p.ldk + max(kcol[i], 0)) * 2u;
+#pragma unroll
+    for (int i = 0; i < VN; ++i) voff[i] = (unsigned)(vrow[i] * p.ldv + max(vcol[i], 0)) * 2u;
     auto load_tile = [&](int kv0) {
+        if (kv0 + 64 <= p.Skv) {   // block-uniform: every row of the tile exists
+            const char* kt_ = (const char*)(Kb + (long long)kv0 * p.ldk);
+            const char* vt_ = (const char*)(Vb + (long long)kv0 * p.ldv);
+#pragma unroll
+            for (int i = 0; i < KN; ++i) {
+                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (kcol[i] >= 0) v = *(const half8*)(kt_ + koff[i]);
+                kreg[i] = v;
+            }
+#pragma unroll
+            for (int i = 0; i < VN; ++i) {
+                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (vcol[i] >= 0) v = *(const half8*)(vt_ + voff[i]);
+                vreg[i] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < KN; ++i) {
             half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -292,13 +315,32 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         if (64 < p.Skv) load_tile(64);
         __syncthreads();
         int buf = 0;
+#ifdef SDE_DIAG
+        unsigned long long st_prev = __builtin_amdgcn_s_memtime(), st_t0 = st_prev, st_r0 = __builtin_amdgcn_s_memrealtime();
+        unsigned st_sum[3] = {0, 0, 0};
+#define STAMP(i) do { unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_sum[i] += (unsigned)(t_ - st_prev); st_prev = t_; } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
         for (int kv0 = 0; kv0 < p.Skv; kv0 += 64, buf ^= 1) {
             if (kv0 + 64 < p.Skv) store_tile(buf ^ 1);     // last read in the previous iteration, which ended with a barrier
             if (kv0 + 128 < p.Skv) load_tile(kv0 + 128);
+            STAMP(0);
             if (kv0 + 64 > p.Skv) tile(kv0, buf, std::true_type{});   // block-uniform branch
             else tile(kv0, buf, std::false_type{});
+            STAMP(1);
             __syncthreads();
+            STAMP(2);
         }
+#ifdef SDE_DIAG
+        if (blockIdx.x == 9 && blockIdx.y == 1 && blockIdx.z == 1 && lane == 0 && p.Skv >= 1024) {
+            const unsigned tot = (unsigned)(__builtin_amdgcn_s_memtime() - st_t0), rt = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+            const int nt = p.Skv / 64;
+            printf("[attn stamps] wave %d: per tile: store+load %u | tile %u | barrier wait %u ; loop %u cycles / %u x10ns = %.2f GHz\n", wid,
+                   st_sum[0] / nt, st_sum[1] / nt, st_sum[2] / nt, tot, rt, tot / (rt * 10.0));
+        }
+#endif
+#undef STAMP
     } else {
         for (int kv0 = 0; kv0 < p.Skv; kv0 += 64) {
             load_tile(kv0);
