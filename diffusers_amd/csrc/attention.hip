@@ -44,8 +44,13 @@ struct AttnDev {
 template <int DQK, int DVT, bool ONES, bool FOLD>
 __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(AttnDev p)
 {
-    constexpr int KROW = DQK + 8;        // padded K-tile row (elements)
-    constexpr int VROW = DVT * 16 + 8;   // padded V-tile row (elements); row stride stays a multiple of 16 B
+    // LDS layouts chosen against the gfx950 bank rules (MI355X_MICROARCH.md, LDS; PMC before: 42 % of LDS cycles were conflicts):
+    //  K, DQK = 64: unpadded 128-B rows with the 16-B chunk index XORed by (row & 7) -> ds_read_b128 conflict-free;
+    //  other DQK keep a one-chunk pad.  V (head dim <= 80): row stride = 32 B x odd -> the two 32-lane halves of
+    //  ds_read_b64_tr_b16 each cover all 64 banks once.
+    constexpr bool KSWZ = DQK == 64;
+    constexpr int KROW = KSWZ ? DQK : DQK + 8;                     // K-tile row (elements)
+    constexpr int VROW = DVT > 5 ? DVT * 16 + 8 : ((DVT & 1) ? DVT * 16 : DVT * 16 + 16);     // V-tile row (elements); wide heads: measured no gain
     constexpr int KS = DQK / 32;         // k-steps of the score product
     constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
     constexpr int NBUF = PREFETCH ? 2 : 1;  // prefetching variants double-buffer the tiles in LDS: one barrier per tile
@@ -109,7 +114,8 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
     for (int i = 0; i < KN; ++i) {
         int idx = tid + i * 256;
         int r = idx / KCH, c = (idx - r * KCH) * 8;
-        krow[i] = r; kcol[i] = (idx < 64 * KCH && c < d) ? c : -1; klds[i] = idx < 64 * KCH ? r * KROW + c : -1;
+        krow[i] = r; kcol[i] = (idx < 64 * KCH && c < d) ? c : -1;
+        klds[i] = idx < 64 * KCH ? r * KROW + (KSWZ ? (((c >> 3) ^ (r & 7)) << 3) : c) : -1;
     }
 #pragma unroll
     for (int i = 0; i < VN; ++i) {
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         for (int i = 0; i < KN; ++i)
             if (kcol[i] < 0 && klds[i] >= 0) {
                 half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (FOLD && klds[i] - krow[i] * KROW == d) { z[0] = (half_t)1.0f; z[1] = (half_t)1.0f; }   // the two max-carrying columns
+                if (FOLD && ((tid + i * 256) % KCH) * 8 == d) { z[0] = (half_t)1.0f; z[1] = (half_t)1.0f; }   // the two max-carrying columns
                 *(half8*)(sK_ + b * 64 * KROW + klds[i]) = z;
             }
 #pragma unroll
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
-                half8 kf = *(const half8*)(sK + (kt * 16 + fr) * KROW + (ks * 4 + fg) * 8);
+                half8 kf = *(const half8*)(sK + (kt * 16 + fr) * KROW + (KSWZ ? (((ks * 4 + fg) ^ (fr & 7)) << 3) : (ks * 4 + fg) * 8));
                 s[kt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[0][ks], s[kt][0], 0, 0, 0);
                 s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
             }

@@ -2,6 +2,7 @@
 """Per-kernel-class summary of a `rocprofv3 --pmc ... --kernel-trace --output-format csv` counter_collection CSV.
 
 usage: python tools/pmc_summary.py <counter_collection.csv> [out.json]
+       python tools/pmc_summary.py --traffic <FETCH_SIZE pass csv> <WRITE_SIZE pass csv> <out.json> [source note]
 
 Counters are summed per kernel class over all dispatches; durations are End-Start of the same dispatches (under PMC
 collection, i.e. slower than un-profiled).  Derived figures:
@@ -41,7 +42,53 @@ def kernel_class(name: str) -> str:
     return base
 
 
+def engine_class(name: str, dur_ns: float, split: dict) -> str:
+    """Engine-profiler class name (what bench.py's kernel table uses).  Self- and cross-attention share kernel instances; they
+    are told apart by duration (self-attention over 4096/1024/256 keys runs several times longer than 77 keys)."""
+    k = kernel_class(name)
+    if k.startswith("attn_mfma"):
+        lo, hi = split.get(k, (dur_ns, dur_ns))
+        if hi > 3 * lo:
+            return "attn_self_mfma" if dur_ns > (lo * hi) ** 0.5 else "attn_cross_mfma"
+        return "attn_self_mfma"
+    if k.startswith("conv3x3_mfma_") or k.startswith("gemm_mfma_"):
+        base, tile = k.rsplit("_", 1)
+        return base if tile in ("128x160", "64x160", "128x128", "64x128") else k
+    m = re.search(r"(gn_stats|gn_apply|gn_small|layernorm|cfg_step|splitk_reduce|gemv)", name)
+    return {"gn_stats": "groupnorm_stats", "gn_apply": "groupnorm_apply", "gn_small": "groupnorm_fused_small", "layernorm": "layernorm",
+            "cfg_step": "cfg_scheduler_step", "splitk_reduce": "splitk_reduce", "gemv": "gemv_time_mlp"}.get(m.group(1), k) if m else k
+
+
+def traffic(fetch_csv: str, write_csv: str, out_path: str, source: str):
+    """profiles/r1_pmc_traffic.json: HBM-side bytes per launch per engine kernel class from two separate --pmc passes."""
+    res = defaultdict(lambda: defaultdict(float))
+    for path, counter, key in ((fetch_csv, "FETCH_SIZE", "fetch_kb"), (write_csv, "WRITE_SIZE", "write_kb")):
+        rows = [r for r in csv.DictReader(open(path, newline="")) if r["Counter_Name"] == counter]
+        split = {}
+        for r in rows:
+            k, d = kernel_class(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            lo, hi = split.get(k, (d, d))
+            split[k] = (min(lo, d), max(hi, d))
+        for r in rows:
+            d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            e = res[engine_class(r["Kernel_Name"], d, split)]
+            e[key] += float(r["Counter_Value"])
+            e[key + "_n"] += 1
+    out = {"source": source, "kernels": {}}
+    for k, e in sorted(res.items(), key=lambda kv: -(kv[1]["fetch_kb"] + kv[1]["write_kb"])):
+        if not e.get("fetch_kb_n") or not e.get("write_kb_n"):
+            continue
+        f = e["fetch_kb"] * 1024 / e["fetch_kb_n"] / 1e6
+        out["kernels"][k] = {"launches": int(e["fetch_kb_n"]), "fetch_MB_per_launch_raw": round(f, 2),
+                             "fetch_MB_per_launch_corrected_x2": round(2 * f, 2),
+                             "write_MB_per_launch": round(e["write_kb"] * 1024 / e["write_kb_n"] / 1e6, 2)}
+    open(out_path, "w").write(json.dumps(out, indent=1) + "\n")
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--traffic":
+        return traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
     path = sys.argv[1]
     agg = defaultdict(lambda: defaultdict(float))
     seen = set()
