@@ -41,21 +41,36 @@ struct AttnDev {
 // FOLD: the head dim leaves spare columns in the score product (d < DQK).  Q is pre-multiplied by scale*log2(e) and two
 // spare columns carry -(running max) as an fp16 hi+lo pair against 1.0 in K, so the MFMA delivers s*c - m*c directly and the
 // per-score VALU work is max + exp2 + cvt (the kernel is VALU-issue-bound at d = 40).
+// LDS layouts, chosen against the gfx950 bank rules (MI355X_MICROARCH.md, LDS; PMC before: 42 % of LDS cycles were conflicts):
+//  K, DQK = 64: unpadded 128-B rows with the 16-B chunk index XORed by (row & 7) -> ds_read_b128 conflict-free; other DQK keep
+//  a one-chunk pad.  V (head dim <= 80): row stride = 32 B x odd -> the two 32-lane halves of ds_read_b64_tr_b16 each cover
+//  all 64 banks once.
+// DMA (head dims 33..64: SD1.x d=40, SD2.x d=64): K/V tiles go global -> LDS directly (buffer_load ... lds) into a 3-deep ring,
+//  two tiles ahead, retired with a counted vmcnt; no staging registers, no ds_write.  Pad chunks (zeros, the FOLD / ONES
+//  constants) are written once per ring slot and never touched again: the DMA lanes that would cover them are masked off.
+template <int DQK, int DVT>
+struct AttnLayout {
+    static constexpr bool KSWZ = DQK == 64;
+    static constexpr int KROW = KSWZ ? DQK : DQK + 8;                     // K-tile row (elements)
+    static constexpr int VROW = DVT > 5 ? DVT * 16 + 8 : ((DVT & 1) ? DVT * 16 : DVT * 16 + 16);     // V-tile row (elements); wide heads: measured no gain
+    static constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
+    static constexpr bool DMA = PREFETCH && DQK == 64;
+    static constexpr int NBUF = DMA ? 3 : (PREFETCH ? 2 : 1);  // the register-staged prefetching variants double-buffer: one barrier per tile
+    static constexpr int SMEM_BYTES = NBUF * 64 * (KROW + VROW) * 2;
+};
+
 template <int DQK, int DVT, bool ONES, bool FOLD>
 __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(AttnDev p)
 {
-    // LDS layouts chosen against the gfx950 bank rules (MI355X_MICROARCH.md, LDS; PMC before: 42 % of LDS cycles were conflicts):
-    //  K, DQK = 64: unpadded 128-B rows with the 16-B chunk index XORed by (row & 7) -> ds_read_b128 conflict-free;
-    //  other DQK keep a one-chunk pad.  V (head dim <= 80): row stride = 32 B x odd -> the two 32-lane halves of
-    //  ds_read_b64_tr_b16 each cover all 64 banks once.
-    constexpr bool KSWZ = DQK == 64;
-    constexpr int KROW = KSWZ ? DQK : DQK + 8;                     // K-tile row (elements)
-    constexpr int VROW = DVT > 5 ? DVT * 16 + 8 : ((DVT & 1) ? DVT * 16 : DVT * 16 + 16);     // V-tile row (elements); wide heads: measured no gain
+    using L = AttnLayout<DQK, DVT>;
+    constexpr bool KSWZ = L::KSWZ, PREFETCH = L::PREFETCH, DMA = L::DMA;
+    constexpr int KROW = L::KROW, VROW = L::VROW, NBUF = L::NBUF;
     constexpr int KS = DQK / 32;         // k-steps of the score product
-    constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
-    constexpr int NBUF = PREFETCH ? 2 : 1;  // prefetching variants double-buffer the tiles in LDS: one barrier per tile
-    __shared__ __attribute__((aligned(16))) half_t sK_[NBUF * 64 * KROW];
-    __shared__ __attribute__((aligned(16))) half_t sV_[NBUF * 64 * VROW];
+    // dynamic LDS through a generic pointer (as the GEMM kernels do): with a static __shared__ array the compiler orders every
+    // ds_read behind ALL outstanding LDS-DMA (s_waitcnt vmcnt(0)), which would serialise the ring
+    extern __shared__ __attribute__((aligned(16))) char attn_smem[];
+    half_t* const sK_ = (half_t*)attn_smem;
+    half_t* const sV_ = sK_ + NBUF * 64 * KROW;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -171,7 +186,7 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
     };
     // pad columns (>= d) never change: written once.  ONES: the very last V column holds 1.0 (softmax denominator).
 #pragma unroll
-    for (int b = 0; b < NBUF; ++b) {
+    for (int b = 0; b < (DMA ? 0 : NBUF); ++b) {
 #pragma unroll
         for (int i = 0; i < KN; ++i)
             if (kcol[i] < 0 && klds[i] >= 0) {
@@ -284,7 +299,30 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         };
         constexpr bool HOLD_V = DVT <= 4;   // keep the V^T fragments in registers for both q-tiles when they fit
         half8 vf[HOLD_V ? 2 : 1][HOLD_V ? DVT : 1];
-        if (HOLD_V) {
+        if constexpr (DMA) {
+            // The transposed reads are issued from inline asm: the compiler orders every ds_read it can see behind ALL outstanding
+            // LDS-DMA (s_waitcnt vmcnt(0)), which would drain the ring's prefetch.  Nothing else touches LDS between here and the
+            // explicit lgkmcnt(0) below, so the compiler's own LDS bookkeeping is not disturbed.
+            fp16x4 vlo[2][DVT], vhi[2][DVT];
+            const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sV + (fg * 4 + tq) * VROW + tp * 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + dt * 16) * 2));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + 16 * VROW + dt * 16) * 2));
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt) {
+                    asm volatile("" : "+v"(vlo[s2][dt]), "+v"(vhi[s2][dt]));   // values are defined only after the wait above
+                    half4 l4 = __builtin_bit_cast(half4, vlo[s2][dt]), h4 = __builtin_bit_cast(half4, vhi[s2][dt]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { vf[HOLD_V ? s2 : 0][HOLD_V ? dt : 0][r] = l4[r]; vf[HOLD_V ? s2 : 0][HOLD_V ? dt : 0][4 + r] = h4[r]; }
+                }
+        } else if (HOLD_V) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -314,6 +352,84 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         }
     };
 
+    if constexpr (DMA) {
+        constexpr int CPR = VROW / 8, VPW = 16 * CPR, NVI = (VPW + 63) / 64, NKI = 2;   // V chunks per row / per wave; DMA instructions per wave
+        const int wu = __builtin_amdgcn_readfirstlane(wid);
+        const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, 0x80000000u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, 0x80000000u, 0x00020000);
+        // lane -> (row, chunk) of the LDS positions it fills; the chunk's source column follows the K swizzle
+        int k_r[NKI], k_cb[NKI], v_r[NVI], v_cb[NVI];
+        unsigned k_off[NKI], v_off[NVI];
+        bool k_act[NKI], v_act[NVI];
+#pragma unroll
+        for (int j = 0; j < NKI; ++j) {
+            const int id = (wu * NKI + j) * 64 + lane, r = id >> 3, c = (id & 7) ^ (r & 7);
+            k_r[j] = r; k_cb[j] = c * 16; k_act[j] = c * 8 < d;
+            k_off[j] = (unsigned)(r * p.ldk * 2 + c * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < NVI; ++j) {
+            const int idw = j * 64 + lane, id = wu * VPW + idw, r = id / CPR, c = id - r * CPR;
+            v_r[j] = r; v_cb[j] = c * 16; v_act[j] = idw < VPW && c * 8 < d;
+            v_off[j] = (unsigned)(r * p.ldv * 2 + c * 16);
+        }
+        auto issue_tile = [&](int kv0, int slot) {
+            char* kd = (char*)(sK_ + slot * 64 * KROW) + wu * NKI * 1024;
+            char* vd = (char*)(sV_ + slot * 64 * VROW) + wu * VPW * 16;
+            const bool full = kv0 + 64 <= p.Skv;     // block-uniform
+            const int ks_ = full ? kv0 * p.ldk * 2 : 0, vs_ = full ? kv0 * p.ldv * 2 : 0;
+#pragma unroll
+            for (int j = 0; j < NKI; ++j) {
+                const unsigned vo = full ? k_off[j] : (unsigned)(min(kv0 + k_r[j], last_key) * p.ldk * 2 + k_cb[j]);
+                if (k_act[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (__attribute__((address_space(3))) void*)(kd + j * 1024), 16, vo, ks_, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NVI; ++j) {
+                const unsigned vo = full ? v_off[j] : (unsigned)(min(kv0 + v_r[j], last_key) * p.ldv * 2 + v_cb[j]);
+                if (v_act[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (__attribute__((address_space(3))) void*)(vd + j * 1024), 16, vo, vs_, 0, 0);
+            }
+        };
+        // pad chunks of all three slots, once
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int id = tid + i * 256, r = id >> 3, c = (id & 7) ^ (r & 7);
+                if (c * 8 >= d) {
+                    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (FOLD && c * 8 == d) { z[0] = (half_t)1.0f; z[1] = (half_t)1.0f; }
+                    *(half8*)(sK_ + b * 64 * KROW + id * 8) = z;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (64 * CPR + 255) / 256; ++i) {
+                const int id = tid + i * 256, r = id / CPR, c = id - r * CPR;
+                if (id < 64 * CPR && c * 8 >= d) {
+                    half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    if (ONES && c == DVT * 2 - 1) z[7] = (half_t)1.0f;
+                    *(half8*)(sV_ + b * 64 * VROW + id * 8) = z;
+                }
+            }
+        }
+        __syncthreads();
+        const int ntile = (p.Skv + 63) >> 6;
+        issue_tile(0, 0);
+        if (ntile > 1) issue_tile(64, 1);
+        int slot = 0;
+        for (int t = 0; t < ntile; ++t) {
+            // this wave's pieces of tile t have landed (tile t+1's NKI+NVI pieces may stay in flight); the barrier then makes the
+            // whole tile visible and tells everyone that slot (t+2)%3 == (t-1)%3 is no longer read
+            if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKI + NVI) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < ntile) issue_tile((t + 2) * 64, slot == 0 ? 2 : slot - 1);
+            const int kv0 = t * 64;
+            if (kv0 + 64 > p.Skv) tile(kv0, slot, std::true_type{});   // block-uniform branch
+            else tile(kv0, slot, std::false_type{});
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    } else
     if (PREFETCH) {
         // tile t is computed from LDS buffer t&1 while tile t+1 moves registers -> the other buffer and tile t+2 is in flight
         load_tile(0);
@@ -434,15 +550,16 @@ template <int DQK, int DVT>
 static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
 {
     dim3 grid(cdiv(p.Sq, 128), p.heads, p.NB);
+    constexpr int smem = AttnLayout<DQK, DVT>::SMEM_BYTES;
     static const int fold_env = getenv("SDE_ATTN_FOLD") ? atoi(getenv("SDE_ATTN_FOLD")) : 1;   // tuning hook
     const bool fold = fold_env && p.d < DQK && DVT <= 4;    // needs two spare score-product columns; wider heads run out of VGPRs (measured slower)
     const bool ones = p.d < DVT * 16;
     if (fold) {
-        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, true>), grid, dim3(256), 0, ctx.stream, p);
-        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, true>), grid, dim3(256), 0, ctx.stream, p);
+        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, true>), grid, dim3(256), smem, ctx.stream, p);
+        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, true>), grid, dim3(256), smem, ctx.stream, p);
     } else {
-        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, false>), grid, dim3(256), 0, ctx.stream, p);
-        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, false>), grid, dim3(256), 0, ctx.stream, p);
+        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, false>), grid, dim3(256), smem, ctx.stream, p);
+        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, false>), grid, dim3(256), smem, ctx.stream, p);
     }
 }
 
