@@ -257,7 +257,7 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
             OnnxModel m; WeightMap w;
             onnx_load(unet_path, m);
             bind_weights(m, w);
-            e->wb.w = &w; e->wb.params = 0;
+            e->wb.w = &w; e->wb.params = 0; e->wb.gelu_tanh = m.fast_gelu;
             e->unet.build(m, w, e->wb, o.num_heads_override);
             HIP_CHECK(hipStreamSynchronize(e->stream));  // repack kernels read mapped files' staging copies
             e->has_unet = true;

@@ -277,7 +277,7 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
     p.Hs = a.ups ? a.Hi / 2 : a.Hi; p.Ws = a.ups ? a.Wi / 2 : a.Wi;
     p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
-    p.epi = a.epi; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
+    p.epi = a.epi; p.gelu_tanh = a.gelu_tanh; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
     p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr; p.stamps = nullptr;
     // fabric reads ~ A + 8*W with column tiles fastest, 8*A + W with row tiles fastest (8 XCDs, each with its own L2)
     {

@@ -300,8 +300,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
                 const int mt = mh * 4 + mq;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * gelu_erf(acc[nt][mt][1] + bvg[nt][0])),
-                                       (half_t)((acc[nt][mt][2] + bvv[nt][1]) * gelu_erf(acc[nt][mt][3] + bvg[nt][1]))};
+                    const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * gelu_sel(acc[nt][mt][1] + bvg[nt][0], p.gelu_tanh)),
+                                       (half_t)((acc[nt][mt][2] + bvv[nt][1]) * gelu_sel(acc[nt][mt][3] + bvg[nt][1], p.gelu_tanh))};
                     *(half2_t*)(wlds + (mq * 16 + fr) * PITCH + (nt * 8 + 2 * fg) * 2) = h;
                 }
             }

@@ -16,7 +16,7 @@ struct GemmDev {
     int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws;
     const half_t* W; int Npad;
     const float* bias; const half_t* R; int ldr;
-    half_t* D; float* Df; int ldd; int epi; float alpha;
+    half_t* D; float* Df; int ldd; int epi; int gelu_tanh; float alpha;
     long long sA, sW, sD, sR;
     const half_t* zeros;
     int nbm, nbn;
@@ -38,6 +38,15 @@ __device__ __forceinline__ float gelu_erf(float x)
     const float e = 1.0f - poly * t * __expf(-z * z);     // erf(|x|/sqrt2)
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
+
+// com.microsoft.FastGelu (what scripts/optimize.py --approximate-gelu leaves in the graph): x * (0.5 + 0.5 * tanh(x * (B + C x^2)))
+__device__ __forceinline__ float gelu_tanh_form(float x)
+{
+    const float u = x * (0.7978845608028654f + 0.035677408136300125f * x * x);
+    const float th = 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * u));      // tanh(u); exp overflow -> 1, underflow -> -1
+    return x * (0.5f + 0.5f * th);
+}
+__device__ __forceinline__ float gelu_sel(float x, int tanh_form) { return tanh_form ? gelu_tanh_form(x) : gelu_erf(x); }
 
 // ------------------------------------------------------------------------------------------ epilogue (shared)
 // Handles 4 consecutive columns n..n+3 of row m held in v[0..3].
@@ -77,7 +86,7 @@ __device__ __forceinline__ void epilogue4(const GemmDev& p, int m, int n, floatx
         for (int r = 0; r < 4; ++r) {
             float a = v[r], g = vg[r];
             if (p.bias && n + r < half_n) { a += p.bias[n + r]; g += p.bias[half_n + n + r]; }
-            h[r] = (half_t)(a * gelu_erf(g));
+            h[r] = (half_t)(a * gelu_sel(g, p.gelu_tanh));
         }
         if (n + 3 < half_n) *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
         else for (int r = 0; r < 4 && n + r < half_n; ++r) p.D[zD + (long long)m * p.ldd + n + r] = h[r];

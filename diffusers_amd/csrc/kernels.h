@@ -60,6 +60,7 @@ struct GemmArgs {
     float* Df = nullptr;
     int ldd = 0;
     int epi = EPI_STD;
+    int gelu_tanh = 0;           // GEGLU epilogues: 1 = com.microsoft.FastGelu's tanh form (optimizer-fused models), 0 = exact erf
     float alpha = 1.0f;
     // batching over blockIdx.z (independent problems with identical shapes)
     int batch = 1;

@@ -289,7 +289,162 @@ static bool ends_with(const std::string& s, const char* suf)
     return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
 }
 
-void bind_weights(const OnnxModel& m, WeightMap& out)
+// ------------------------------------------------------------------------------------------ optimizer-fused dialect
+// scripts/optimize.py (--preset gpu*) rewrites the exported graphs with onnxruntime's transformer fusions.  Convolutions, plain
+// MatMuls, LayerNorm gamma/beta and biases keep their names; what loses its module name is handled here:
+//   com.microsoft.Attention      weight [C,3C] = np.stack((q,k,v), axis=1), bias [3C]     (fusion_attention_unet.py:215-226,
+//                                                                                          fusion_attention_vae.py:160-190)
+//   MatMul_KV_n / MatMul_QKV_n   weight [Cin, heads*2*d] / [C, heads*3*d], per-head interleave   (fusion_attention_unet.py:164-280)
+//   com.microsoft.GroupNorm      gamma / beta as <node>_gamma / <node>_beta                       (fusion_group_norm.py:108-160)
+//   com.microsoft.FastGelu       tanh-form GELU in place of the exact one                         (fusion_gelu_approximation.py)
+// The module a fused node belongs to is read off the first NAMED node that consumes its result (to_out.0 / proj_attn / conv1 ...).
+namespace {
+struct FusedBinder {
+    OnnxModel& m;
+    WeightMap& out;
+    std::unordered_map<std::string, std::vector<int>> consumers;
+
+    explicit FusedBinder(OnnxModel& m_, WeightMap& o) : m(m_), out(o)
+    {
+        for (int i = 0; i < (int)m.nodes.size(); ++i)
+            for (auto& in : m.nodes[(size_t)i].inputs) consumers[in].push_back(i);
+    }
+    static bool named(const OnnxNode& n)
+    {
+        if (n.name.size() < 2 || n.name[0] != '/') return false;
+        return n.op_type == "MatMul" || n.op_type == "Conv" || n.op_type == "Gemm";
+    }
+    // module ("a.b.c") of the first named MatMul / Conv / Gemm reachable from `tensor` through unnamed nodes (breadth first)
+    std::string consumer_module(const std::string& tensor) const
+    {
+        std::vector<std::string> frontier{tensor};
+        for (int depth = 0; depth < 8 && !frontier.empty(); ++depth) {
+            std::vector<std::string> next;
+            for (auto& t : frontier) {
+                auto it = consumers.find(t);
+                if (it == consumers.end()) continue;
+                for (int ni : it->second) {
+                    const OnnxNode& n = m.nodes[(size_t)ni];
+                    if (named(n)) return module_of(n.name);
+                    for (auto& o : n.outputs) next.push_back(o);
+                }
+            }
+            frontier.swap(next);
+        }
+        return "";
+    }
+    static std::string parent(const std::string& mod, const char* suffix)
+    {
+        size_t n = strlen(suffix);
+        return mod.size() > n && mod.compare(mod.size() - n, n, suffix) == 0 ? mod.substr(0, mod.size() - n) : "";
+    }
+    const OnnxTensor* init(const std::string& name) const
+    {
+        auto it = m.initializers.find(name);
+        return it == m.initializers.end() ? nullptr : &it->second;
+    }
+    // columns [c0 + g*gstride, +glen) for g = 0..groups-1 of a row-major [rows][cols] tensor -> new [rows][groups*glen] tensor
+    const OnnxTensor* take_columns(const OnnxTensor& src, int64_t c0, int64_t glen, int64_t gstride, int64_t groups, const std::string& name)
+    {
+        SDE_REQUIRE(src.dims.size() == 2 && src.data, SDE_ERR_MODEL, "fused weight " + src.name + " is not a 2-D tensor with data");
+        const int64_t rows = src.dims[0], cols = src.dims[1];
+        const size_t es = dtype_size(src.data_type);
+        SDE_REQUIRE(es && c0 + (groups - 1) * gstride + glen <= cols && src.nbytes >= (size_t)(rows * cols) * es, SDE_ERR_MODEL,
+                    "fused weight " + src.name + " has an unexpected shape");
+        m.synth.emplace_back();
+        OnnxTensor& t = m.synth.back();
+        t.name = name; t.data_type = src.data_type; t.dims = {rows, groups * glen};
+        t.owned.resize((size_t)(rows * groups * glen) * es);
+        for (int64_t r = 0; r < rows; ++r)
+            for (int64_t g = 0; g < groups; ++g)
+                memcpy(t.owned.data() + (size_t)((r * groups + g) * glen) * es, src.data + (size_t)(r * cols + c0 + g * gstride) * es, (size_t)glen * es);
+        t.data = t.owned.data(); t.nbytes = t.owned.size();
+        return &t;
+    }
+    const OnnxTensor* take_range(const OnnxTensor& src, int64_t e0, int64_t n, const std::string& name)
+    {
+        const size_t es = dtype_size(src.data_type);
+        SDE_REQUIRE(es && src.data && src.nbytes >= (size_t)(e0 + n) * es, SDE_ERR_MODEL, "fused bias " + src.name + " is too short");
+        m.synth.emplace_back();
+        OnnxTensor& t = m.synth.back();
+        t.name = name; t.data_type = src.data_type; t.dims = {n};
+        t.owned.assign(src.data + (size_t)e0 * es, src.data + (size_t)(e0 + n) * es);
+        t.data = t.owned.data(); t.nbytes = t.owned.size();
+        return &t;
+    }
+    static int num_heads(const OnnxNode& n) { const OnnxAttr* a = n.attr("num_heads"); return a ? (int)a->i : 0; }
+
+    void run()
+    {
+        for (auto& n : m.nodes) {
+            const bool ms = n.domain == "com.microsoft";
+            if (ms && n.op_type == "FastGelu") { m.fused = m.fast_gelu = true; continue; }
+            if (ms && (n.op_type == "Attention" || n.op_type == "MultiHeadAttention" || n.op_type == "GroupNorm")) m.fused = true;
+            if (ms && n.op_type == "Attention" && n.inputs.size() >= 2 && !n.outputs.empty()) {
+                const OnnxTensor* W = init(n.inputs[1]);
+                if (!W) continue;                               // packed-QKV form: the weight sits on MatMul_QKV_n (below)
+                const std::string mod = consumer_module(n.outputs[0]);
+                std::string scope = parent(mod, ".to_out.0");
+                const bool vae = scope.empty();
+                if (vae) scope = parent(mod, ".proj_attn");
+                SDE_REQUIRE(!scope.empty(), SDE_ERR_MODEL, "fused Attention node " + n.name + ": cannot find the module it belongs to");
+                SDE_REQUIRE(W->dims.size() == 2 && W->dims[1] == 3 * W->dims[0], SDE_ERR_MODEL, "fused Attention node " + n.name + ": weight is not [C,3C]");
+                const int64_t C = W->dims[0];
+                const char* names_u[3] = {".to_q", ".to_k", ".to_v"};
+                const char* names_v[3] = {".query", ".key", ".value"};
+                const OnnxTensor* B = n.inputs.size() >= 3 ? init(n.inputs[2]) : nullptr;
+                for (int j = 0; j < 3; ++j) {
+                    const std::string key = scope + (vae ? names_v[j] : names_u[j]);
+                    out[key + ".weight"] = BoundTensor{take_columns(*W, j * C, C, 0, 1, key + ".weight"), true};
+                    if (vae && B) out[key + ".bias"] = BoundTensor{take_range(*B, j * C, C, key + ".bias"), false};
+                }
+                if (num_heads(n) > 0) m.fused_heads[scope] = num_heads(n);
+            } else if (ms && n.op_type == "MultiHeadAttention" && !n.outputs.empty()) {
+                const std::string scope = parent(consumer_module(n.outputs[0]), ".to_out.0");
+                if (!scope.empty() && num_heads(n) > 0) m.fused_heads[scope] = num_heads(n);
+            } else if (n.op_type == "MatMul" && (n.name.rfind("MatMul_KV", 0) == 0 || n.name.rfind("MatMul_QKV", 0) == 0) && n.inputs.size() == 2) {
+                const int parts = n.name.rfind("MatMul_QKV", 0) == 0 ? 3 : 2;
+                const OnnxTensor* W = init(n.inputs[1]);
+                const OnnxTensor* shp = init(n.name + "_reshape_shape");      // [0, 0, heads, parts, d]
+                SDE_REQUIRE(W && shp && shp->data_type == 7 && shp->nbytes >= 40, SDE_ERR_MODEL, "packed " + n.name + ": weight or reshape shape missing");
+                int64_t sv[5];
+                memcpy(sv, shp->data, 40);
+                const int64_t heads = sv[2], d = sv[4];
+                SDE_REQUIRE(heads > 0 && d > 0 && sv[3] == parts && W->dims.size() == 2 && W->dims[1] == heads * parts * d, SDE_ERR_MODEL,
+                            "packed " + n.name + ": shape does not match [in, heads*" + std::to_string(parts) + "*d]");
+                const std::string scope = parent(consumer_module(n.outputs[0]), ".to_out.0");
+                SDE_REQUIRE(!scope.empty(), SDE_ERR_MODEL, "packed " + n.name + ": cannot find the attention it feeds");
+                const char* names2[2] = {".to_k", ".to_v"};
+                const char* names3[3] = {".to_q", ".to_k", ".to_v"};
+                for (int j = 0; j < parts; ++j) {
+                    const std::string key = scope + (parts == 2 ? names2[j] : names3[j]) + ".weight";
+                    out[key] = BoundTensor{take_columns(*W, j * d, d, parts * d, heads, key), true};
+                }
+                m.fused_heads[scope] = (int)heads;
+            } else if (ms && n.op_type == "GroupNorm" && n.inputs.size() >= 3 && !n.outputs.empty()) {
+                const OnnxTensor* g = init(n.inputs[1]);
+                const OnnxTensor* b = init(n.inputs[2]);
+                SDE_REQUIRE(g && b, SDE_ERR_MODEL, "fused GroupNorm node " + n.name + ": gamma / beta are not initializers");
+                const std::string mod = consumer_module(n.outputs[0]);
+                std::string key;
+                std::string s;
+                if (!(s = parent(mod, ".conv1")).empty()) key = s + ".norm1";
+                else if (!(s = parent(mod, ".conv2")).empty()) key = s + ".norm2";
+                else if (!(s = parent(mod, ".proj_in")).empty()) key = s + ".norm";
+                else if (!(s = parent(mod, ".proj_attn")).empty()) key = s + ".group_norm";
+                else if (!(s = parent(mod, ".query")).empty()) key = s + ".group_norm";
+                else if (mod == "conv_out") key = "conv_norm_out";
+                else if (!(s = parent(mod, ".conv_out")).empty()) key = s + ".conv_norm_out";
+                SDE_REQUIRE(!key.empty(), SDE_ERR_MODEL, "fused GroupNorm node " + n.name + ": unexpected consumer '" + mod + "'");
+                out[key + ".weight"] = BoundTensor{g, false};
+                out[key + ".bias"] = BoundTensor{b, false};
+            }
+        }
+    }
+};
+}  // namespace
+
+void bind_weights(OnnxModel& m, WeightMap& out)
 {
     std::unordered_map<std::string, std::string> alias;
     for (auto& n : m.nodes)
@@ -322,6 +477,7 @@ void bind_weights(const OnnxModel& m, WeightMap& out)
             }
         }
     }
+    FusedBinder(m, out).run();
 }
 
 int onnx_attention_head_dim(const OnnxModel& m, const std::string& scope)

@@ -2,6 +2,7 @@
 // Replaces what `SessionBuilder::with_model_from_file` does for the reference
 // (/root/reference/src/pipelines/stable_diffusion/impl_main.rs:136-157) for the two graphs on the hot path.
 #pragma once
+#include <deque>
 #include <map>
 #include <memory>
 #include <string>
@@ -52,6 +53,12 @@ struct OnnxModel {
     std::unordered_map<std::string, OnnxTensor> initializers;
     std::vector<std::string> inputs, outputs;
     std::vector<std::unique_ptr<MappedFile>> files;  // keep mappings alive
+    // filled by bind_weights for the optimizer-fused dialect (scripts/optimize.py): per-module tensors unpacked from the packed
+    // Attention / MatMul_KV weights (std::deque: stable addresses), head counts of the fused attention nodes by module scope,
+    // and whether the feed-forward GELU was replaced by com.microsoft.FastGelu (tanh form)
+    std::deque<OnnxTensor> synth;
+    std::map<std::string, int> fused_heads;
+    bool fused = false, fast_gelu = false;
 };
 void onnx_load(const std::string& path, OnnxModel& out);
 
@@ -72,6 +79,6 @@ struct BoundTensor {
     int64_t in_dim() const { return in_out ? t->dims[0] : t->dims[1]; }
 };
 typedef std::unordered_map<std::string, BoundTensor> WeightMap;
-void bind_weights(const OnnxModel& m, WeightMap& out);
+void bind_weights(OnnxModel& m, WeightMap& out);
 // head dim of the first attention whose node names start with `scope` (from the softmax scale constant); 0 if absent
 int onnx_attention_head_dim(const OnnxModel& m, const std::string& scope);

@@ -126,6 +126,7 @@ void linear(Exec& ex, const DevLinear& L, const half_t* A, int lda, int M, half_
     g.M = M; g.N = L.N; g.K = L.K; g.taps = 1;
     g.W = L.W; g.Npad = L.Npad; g.bias = L.bias; g.R = R; g.ldr = ldr; g.D = D; g.ldd = ldd;
     g.epi = L.geglu ? (L.geglu_pair ? EPI_GEGLU_PAIR : EPI_GEGLU) : EPI_STD;
+    g.gelu_tanh = L.gelu_tanh ? 1 : 0;
     SDE_REQUIRE(L.taps == 1 && g.C0 + g.C1 == L.K, SDE_ERR_MODEL, "linear: operand width mismatch");
     run_gemm(ex, g);
 }
@@ -261,6 +262,7 @@ TransformerW build_transformer(WeightBuilder& b, const std::string& p, int heads
     t.kv2 = b.linear({k + ".attn2.to_k.weight", k + ".attn2.to_v.weight"}, {});
     t.out2 = b.linear({k + ".attn2.to_out.0.weight"}, {k + ".attn2.to_out.0.bias"});
     t.ff1 = b.linear({k + ".ff.net.0.proj.weight"}, {k + ".ff.net.0.proj.bias"}, 0, true);
+    t.ff1.gelu_tanh = b.gelu_tanh;
     t.ff2 = b.linear({k + ".ff.net.2.weight"}, {k + ".ff.net.2.bias"});
     t.C = t.proj_in.N; t.heads = heads;
     SDE_REQUIRE(t.C % heads == 0, SDE_ERR_MODEL, "transformer " + p + ": width not divisible by head count");
@@ -299,6 +301,12 @@ void UNetModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b, 
         std::string scope = down_attn[i] ? "/down_blocks." + std::to_string(i) + "/attentions.0/transformer_blocks.0/attn1/"
                                          : "/mid_block/attentions.0/transformer_blocks.0/attn1/";
         hd = onnx_attention_head_dim(m, scope);
+        {   // optimizer-fused dialect: the softmax scale constant is gone, the fused node carries num_heads
+            std::string key;
+            for (size_t c = 1; c + 1 < scope.size(); ++c) key += scope[c] == '/' ? '.' : scope[c];
+            auto it = m.fused_heads.find(key);
+            if (it != m.fused_heads.end() && it->second > 0 && boc[i] % it->second == 0) hd = boc[i] / it->second;
+        }
         if (hd <= 0 || boc[i] % hd) hd = ctx_dim == 1024 ? 64 : boc[i] / 8;  // SD2.x: d=64 ; SD1.x: 8 heads
         heads.push_back(boc[i] / hd);
     }

@@ -31,6 +31,7 @@ struct DevLinear {
     float* bias = nullptr;
     int N = 0, Npad = 0, K = 0, taps = 1, Cin = 0;  // Cin = (padded) channels per tap
     bool geglu = false, geglu_pair = false;   // geglu_pair: pairwise value/gate row interleave (EPI_GEGLU_PAIR)
+    bool gelu_tanh = false;                   // GEGLU with FastGelu's tanh form (optimizer-fused model dirs)
 };
 struct DevNorm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 
@@ -106,6 +107,7 @@ struct VaeDecoderModel {
 
 // uploads + repacks weights; owns every device allocation it makes
 struct WeightBuilder {
+    bool gelu_tanh = false;     // the model being built came from the optimizer with --approximate-gelu (FastGelu nodes)
     LaunchCtx ctx;
     const WeightMap* w = nullptr;
     std::vector<void*> allocs;

@@ -257,22 +257,35 @@ def _attr_t(name, tensor_bytes):
     return _ld(5, _ld(1, name.encode()) + _ld(5, tensor_bytes) + _iv(20, 4))
 
 
-def _node(op, name, inputs, outputs, attrs=b""):
+def _node(op, name, inputs, outputs, attrs=b"", domain=""):
     b = b"".join(_ld(1, i.encode()) for i in inputs) + b"".join(_ld(2, o.encode()) for o in outputs)
-    return _ld(3, name.encode()) + _ld(4, op.encode()) + b + attrs
+    return _ld(3, name.encode()) + _ld(4, op.encode()) + b + attrs + (_ld(7, domain.encode()) if domain else b"")
 
 
 class GraphWriter:
     """Accumulates nodes/initializers; weights above ``external_threshold`` bytes total go to one
     external file, as sd2pyke.py:306-316 does for > 2000 MB UNets."""
 
-    def __init__(self, dtype=np.float32):
+    def __init__(self, dtype=np.float32, fused: bool = False, approximate_gelu: bool = False):
+        """``fused``: emit the graph the reference's optimizer leaves behind (scripts/optimize.py --preset gpu:
+        com.microsoft Attention / MultiHeadAttention with packed KV / GroupNorm, LayerNormalization, Gelu or FastGelu) instead
+        of the raw torch export.  Weight packing follows scripts/_optimizer/fusion_attention_unet.py:215-226,231-280,
+        fusion_attention_vae.py:160-190, fusion_group_norm.py:108-160."""
         self.nodes: List[bytes] = []
         self.inits: List[Tuple[str, np.ndarray]] = []
         self.counter = 100
         self.dtype = np.dtype(dtype)
         self.val = 0
         self.cidx = 0
+        self.fused = fused
+        self.approximate_gelu = approximate_gelu
+        self.fcount: Dict[str, int] = {}
+
+    def fname(self, prefix: str) -> str:
+        """OnnxModel.create_node_name: <prefix>_<running index>."""
+        i = self.fcount.get(prefix, 0)
+        self.fcount[prefix] = i + 1
+        return f"{prefix}_{i}"
 
     def anon(self, kind: str) -> str:
         self.counter += 1
@@ -287,8 +300,8 @@ class GraphWriter:
             arr = arr.astype(self.dtype)
         self.inits.append((name, arr))
 
-    def node(self, op, name, inputs, outputs, attrs=b""):
-        self.nodes.append(_node(op, name, inputs, outputs, attrs))
+    def node(self, op, name, inputs, outputs, attrs=b"", domain=""):
+        self.nodes.append(_node(op, name, inputs, outputs, attrs, domain))
 
     def const(self, scope, value: np.ndarray) -> str:
         self.cidx += 1
@@ -329,7 +342,18 @@ class GraphWriter:
                   _attr_f("alpha", 1.0) + _attr_f("beta", 1.0) + _attr_i("transB", 1))
         return out
 
-    def group_norm(self, scope, pname, w, x, eps, groups=32):
+    def group_norm(self, scope, pname, w, x, eps, groups=32, swish=False):
+        if self.fused:
+            # fusion_group_norm.py: Transpose(NCHW->NHWC) -> com.microsoft.GroupNorm(gamma, beta; activation = swish) -> Transpose
+            name = self.fname("GroupNorm")
+            self.init(name + "_gamma", w[pname + ".weight"].reshape(-1))
+            self.init(name + "_beta", w[pname + ".bias"].reshape(-1))
+            self.node("Transpose", self.fname("Transpose_NCHW_to_NHWC"), [x], [x + "_NHWC"], _attr_ints("perm", [0, 2, 3, 1]))
+            out = self.tmp(scope, "Mul" if swish else "Add")
+            self.node("GroupNorm", name, [x + "_NHWC", name + "_gamma", name + "_beta"], [out + "_NHWC"],
+                      _attr_f("epsilon", eps) + _attr_i("groups", groups) + _attr_i("activation", 1 if swish else 0), "com.microsoft")
+            self.node("Transpose", self.fname("Transpose_NHWC_to_NCHW"), [out + "_NHWC"], [out], _attr_ints("perm", [0, 3, 1, 2]))
+            return out
         shp = self.const(scope, np.asarray([0, groups, -1], np.int64))
         r = self.tmp(scope, "Reshape")
         self.node("Reshape", f"{scope}/Reshape", [x, shp], [r])
@@ -354,6 +378,11 @@ class GraphWriter:
         """opset-15 decomposed LayerNorm with named gamma/beta."""
         self.init(pname + ".weight", w[pname + ".weight"])
         self.init(pname + ".bias", w[pname + ".bias"])
+        if self.fused:   # fusion_layernorm.py: one LayerNormalization node that keeps the named gamma / beta
+            out = self.tmp(scope, "Add_1")
+            self.node("LayerNormalization", self.fname("LayerNorm"), [x, pname + ".weight", pname + ".bias"], [out],
+                      _attr_i("axis", -1) + _attr_f("epsilon", eps))
+            return out
         mu = self.tmp(scope, "ReduceMean")
         self.node("ReduceMean", f"{scope}/ReduceMean", [x], [mu], _attr_ints("axes", [-1]))
         d = self.tmp(scope, "Sub")
@@ -426,6 +455,18 @@ class GraphWriter:
 
 
 def _emit_resnet(gw: GraphWriter, scope, p, w, x, emb, eps, groups):
+    if gw.fused:   # the swish after each GroupNorm is folded into the node (activation = 1)
+        h = gw.group_norm(scope + "/norm1", p + ".norm1", w, x, eps, groups, swish=True)
+        h = gw.conv(scope + "/conv1", p + ".conv1", w, h)
+        if emb is not None and (p + ".time_emb_proj.weight") in w:
+            e = gw.silu(scope + "/nonlinearity_1", emb)
+            e = gw.gemm(scope + "/time_emb_proj", p + ".time_emb_proj", w, e)
+            h = gw.binary("Add", scope, h, e)
+        h = gw.group_norm(scope + "/norm2", p + ".norm2", w, h, eps, groups, swish=True)
+        h = gw.conv(scope + "/conv2", p + ".conv2", w, h)
+        if (p + ".conv_shortcut.weight") in w:
+            x = gw.conv(scope + "/conv_shortcut", p + ".conv_shortcut", w, x, k=1)
+        return gw.binary("Add", scope, x, h, "Add_1")
     h = gw.group_norm(scope + "/norm1", p + ".norm1", w, x, eps, groups)
     h = gw.silu(scope + "/nonlinearity", h)
     h = gw.conv(scope + "/conv1", p + ".conv1", w, h)
@@ -442,7 +483,34 @@ def _emit_resnet(gw: GraphWriter, scope, p, w, x, emb, eps, groups):
     return gw.binary("Div", scope, s, gw.const(scope, np.asarray(1.0, np.float32)))
 
 
+def _emit_attention_fused(gw: GraphWriter, scope, p, w, x, ctx, heads, c):
+    """fusion_attention_unet.py: self-attention -> com.microsoft.Attention with one [C, 3C] weight (np.stack((q,k,v), axis=1)) and a
+    zero bias; cross-attention -> to_q MatMul kept, K/V weights interleaved per head into MatMul_KV_n (np.dstack of [c, n, h]),
+    Reshape to [0, 0, n, 2, h], com.microsoft.MultiHeadAttention(query, packed kv)."""
+    qw, kw, vw = (np.ascontiguousarray(w[p + f".to_{t}.weight"].T) for t in "qkv")   # [in, out] as MatMul stores them
+    d = c // heads
+    out = gw.tmp(scope, "Reshape_7")
+    if x == ctx:
+        name = gw.fname("Attention")
+        gw.init(name + "_qkv_weight", np.stack((qw, kw, vw), axis=1).reshape(qw.shape[0], 3 * qw.shape[1]))
+        gw.init(name + "_qkv_bias", np.zeros(3 * c, np.float32))
+        gw.node("Attention", name, [x, name + "_qkv_weight", name + "_qkv_bias"], [out], _attr_i("num_heads", heads), "com.microsoft")
+    else:
+        q = gw.linear(scope + "/to_q", p + ".to_q", w, x, bias=False)
+        mm = gw.fname("MatMul_KV")
+        cin = kw.shape[0]
+        gw.init(mm + "_weight", np.dstack([kw.reshape(cin, heads, d), vw.reshape(cin, heads, d)]).reshape(cin, heads * 2 * d))
+        gw.node("MatMul", mm, [ctx, mm + "_weight"], [mm + "_out"])
+        gw.inits.append((mm + "_reshape_shape", np.asarray([0, 0, heads, 2, d], np.int64)))
+        kout = gw.tmp(scope + "/to_k", "MatMul")
+        gw.node("Reshape", mm + "_reshape", [mm + "_out", mm + "_reshape_shape"], [kout])
+        gw.node("MultiHeadAttention", gw.fname("MultiHeadAttention"), [q, kout], [out], _attr_i("num_heads", heads), "com.microsoft")
+    return gw.linear(scope + "/to_out.0", p + ".to_out.0", w, out, bias=True)
+
+
 def _emit_attention(gw: GraphWriter, scope, p, w, x, ctx, heads, c):
+    if gw.fused:
+        return _emit_attention_fused(gw, scope, p, w, x, ctx, heads, c)
     q = gw.linear(scope + "/to_q", p + ".to_q", w, x, bias=False)
     k = gw.linear(scope + "/to_k", p + ".to_k", w, ctx, bias=False)
     v = gw.linear(scope + "/to_v", p + ".to_v", w, ctx, bias=False)
@@ -469,18 +537,28 @@ def _emit_transformer(gw: GraphWriter, scope, p, w, x, ctx, heads, c, lin, group
     h = gw.binary("Add", bs, h, _emit_attention(gw, bs + "/attn2", bp + ".attn2", w, n, ctx, heads, c), "Add_1")
     n = gw.layer_norm(bs + "/norm3", bp + ".norm3", w, h)
     y = gw.linear(bs + "/ff/net.0/proj", bp + ".ff.net.0.proj", w, n)
-    # exact-erf GELU on the gate half (fusion_gelu.py:27-45 pattern), value half first
-    g = gw.binary("Div", bs + "/ff/net.0", y, gw.const(bs, np.asarray(1.4142135381698608, np.float32)))
-    g = gw.unary("Erf", bs + "/ff/net.0", g)
-    y = gw.binary("Mul", bs + "/ff/net.0", y, g)
+    if gw.fused:
+        # fusion_gelu.py -> Gelu ; with --approximate-gelu fusion_gelu_approximation.py turns it into com.microsoft.FastGelu (tanh form)
+        g = gw.tmp(bs + "/ff/net.0", "Mul_3")
+        if gw.approximate_gelu:
+            gw.node("FastGelu", gw.fname("FastGelu_Gelu_Approximation"), [y], [g], b"", "com.microsoft")
+        else:
+            gw.node("Gelu", gw.fname("Gelu"), [y], [g], b"", "com.microsoft")
+        y = gw.binary("Mul", bs + "/ff/net.0", y, g)
+    else:
+        # exact-erf GELU on the gate half (fusion_gelu.py:27-45 pattern), value half first
+        g = gw.binary("Div", bs + "/ff/net.0", y, gw.const(bs, np.asarray(1.4142135381698608, np.float32)))
+        g = gw.unary("Erf", bs + "/ff/net.0", g)
+        y = gw.binary("Mul", bs + "/ff/net.0", y, g)
     y = gw.linear(bs + "/ff/net.2", bp + ".ff.net.2", w, y)
     h = gw.binary("Add", bs, h, y, "Add_2")
     h = gw.linear(scope + "/proj_out", p + ".proj_out", w, h) if lin else gw.conv(scope + "/proj_out", p + ".proj_out", w, h, k=1)
     return gw.binary("Add", scope, h, x)
 
 
-def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32, external: bool | None = None):
-    gw = GraphWriter(dtype)
+def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32, external: bool | None = None,
+                    fused: bool = False, approximate_gelu: bool = False):
+    gw = GraphWriter(dtype, fused, approximate_gelu)
     boc = list(cfg["block_out_channels"])
     lpb, lin, groups, eps = cfg["layers_per_block"], cfg["use_linear_projection"], cfg["norm_num_groups"], cfg["norm_eps"]
     t = gw.unary("Cast", "", "timestep")
@@ -524,8 +602,9 @@ def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.flo
                     _attr_s("coordinate_transformation_mode", "asymmetric") + _attr_s("mode", "nearest") +
                     _attr_s("nearest_mode", "floor"))
             h = gw.conv(sc + "/conv", f"up_blocks.{i}.upsamplers.0.conv", w, r)
-    h = gw.group_norm("/conv_norm_out", "conv_norm_out", w, h, eps, groups)
-    h = gw.silu("/conv_act", h)
+    h = gw.group_norm("/conv_norm_out", "conv_norm_out", w, h, eps, groups, swish=True)
+    if not gw.fused:
+        h = gw.silu("/conv_act", h)
     out = gw.conv("/conv_out", "conv_out", w, h)
     gw.node("Cast", "/Cast_out", [out], ["out_sample"], _attr_i("to", 1))
     nbytes = sum(a.nbytes for _, a in gw.inits)
@@ -534,8 +613,8 @@ def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.flo
     gw.serialize(path, ["sample", "timestep", "encoder_hidden_states"], ["out_sample"], "unet_weights.bin" if external else None)
 
 
-def write_vae_decoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32):
-    gw = GraphWriter(dtype)
+def write_vae_decoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32, fused: bool = False):
+    gw = GraphWriter(dtype, fused)
     groups = cfg["norm_num_groups"]
     boc = list(reversed(cfg["block_out_channels"]))
     z = gw.conv("/post_quant_conv", "post_quant_conv", w, "latent_sample", k=1)
@@ -544,13 +623,23 @@ def write_vae_decoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype
     sc, p = "/decoder/mid_block/attentions.0", "decoder.mid_block.attentions.0"
     c = boc[0]
     n = gw.group_norm(sc + "/group_norm", p + ".group_norm", w, h, 1e-6, groups)
-    q = gw.linear(sc + "/query", p + ".query", w, n)
-    k = gw.linear(sc + "/key", p + ".key", w, n)
-    v = gw.linear(sc + "/value", p + ".value", w, n)
-    s = gw.binary("MatMul", sc, q, k)
-    s = gw.binary("Mul", sc, s, gw.const(sc, np.asarray(c ** -0.5, np.float32)), "Mul_1")
-    s = gw.unary("Softmax", sc, s)
-    o = gw.binary("MatMul", sc, s, v, "MatMul_1")
+    if gw.fused:
+        # fusion_attention_vae.py:160-190: one Attention node, weight np.stack((q,k,v), axis=1); REFERENCE_QUIRK: the q/k/v biases
+        # are stacked and then overwritten with zeros (:182-183), so the fused decoder runs without them
+        qw, kw, vw = (np.ascontiguousarray(w[p + f".{t}.weight"].T) for t in ("query", "key", "value"))
+        name = gw.fname("Attention")
+        gw.init(name + "_qkv_weight", np.stack((qw, kw, vw), axis=1).reshape(c, 3 * c))
+        gw.init(name + "_qkv_bias", np.zeros(3 * c, np.float32))
+        o = gw.tmp(sc, "Reshape_3")
+        gw.node("Attention", name, [n, name + "_qkv_weight", name + "_qkv_bias"], [o], _attr_i("num_heads", 1), "com.microsoft")
+    else:
+        q = gw.linear(sc + "/query", p + ".query", w, n)
+        k = gw.linear(sc + "/key", p + ".key", w, n)
+        v = gw.linear(sc + "/value", p + ".value", w, n)
+        s = gw.binary("MatMul", sc, q, k)
+        s = gw.binary("Mul", sc, s, gw.const(sc, np.asarray(c ** -0.5, np.float32)), "Mul_1")
+        s = gw.unary("Softmax", sc, s)
+        o = gw.binary("MatMul", sc, s, v, "MatMul_1")
     o = gw.linear(sc + "/proj_attn", p + ".proj_attn", w, o)
     h = gw.binary("Add", sc, o, h)
     h = _emit_resnet(gw, "/decoder/mid_block/resnets.1", "decoder.mid_block.resnets.1", w, h, None, 1e-6, groups)
@@ -564,8 +653,9 @@ def write_vae_decoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype
                     _attr_s("coordinate_transformation_mode", "asymmetric") + _attr_s("mode", "nearest") +
                     _attr_s("nearest_mode", "floor"))
             h = gw.conv(s2 + "/conv", f"decoder.up_blocks.{i}.upsamplers.0.conv", w, r)
-    h = gw.group_norm("/decoder/conv_norm_out", "decoder.conv_norm_out", w, h, 1e-6, groups)
-    h = gw.silu("/decoder/conv_act", h)
+    h = gw.group_norm("/decoder/conv_norm_out", "decoder.conv_norm_out", w, h, 1e-6, groups, swish=True)
+    if not gw.fused:
+        h = gw.silu("/decoder/conv_act", h)
     out = gw.conv("/decoder/conv_out", "decoder.conv_out", w, h)
     gw.node("Cast", "/Cast_out", [out], ["sample"], _attr_i("to", 1))
     gw.serialize(path, ["latent_sample"], ["sample"], None)
@@ -607,15 +697,15 @@ vae-decoder = "{vae_hash}"
 
 
 def write_model_dir(root: str, unet_cfg: dict, vae_cfg: dict, seed: int = 42, dtype=np.float32,
-                    unet_gain: float = 1.0, external: bool | None = None):
+                    unet_gain: float = 1.0, external: bool | None = None, fused: bool = False, approximate_gelu: bool = False):
     """Writes pyke-diffusers.toml + unet.onnx(+unet_weights.bin) + vae_decoder.onnx with random weights.
     The text-encoder/tokenizer entries are placeholders: CLIP stays with the caller."""
     os.makedirs(root, exist_ok=True)
     uw = random_weights(unet_param_shapes(unet_cfg), seed, unet_gain)
-    write_unet_onnx(os.path.join(root, "unet.onnx"), unet_cfg, uw, dtype, external)
+    write_unet_onnx(os.path.join(root, "unet.onnx"), unet_cfg, uw, dtype, external, fused, approximate_gelu)
     del uw
     vw = random_weights(vae_decoder_param_shapes(vae_cfg), seed + 1)
-    write_vae_decoder_onnx(os.path.join(root, "vae_decoder.onnx"), vae_cfg, vw, dtype)
+    write_vae_decoder_onnx(os.path.join(root, "vae_decoder.onnx"), vae_cfg, vw, dtype, fused)
     with open(os.path.join(root, "pyke-diffusers.toml"), "w") as f:
         f.write(TOML_TEMPLATE.format(unet_hash=f"{seed:032x}", vae_hash=f"{seed + 1:032x}"))
     return root

@@ -104,7 +104,8 @@ def attention(x: T, ctx: T, w, p: str, heads: int) -> T:
     return linear(o, w, p + ".to_out.0")
 
 
-def transformer(x: T, ctx: T, w, p: str, heads: int, groups: int, linear_proj: bool) -> T:
+def transformer(x: T, ctx: T, w, p: str, heads: int, groups: int, linear_proj: bool, gelu_approximate: str = "none") -> T:
+    """``gelu_approximate='tanh'``: the graph after scripts/optimize.py --approximate-gelu (com.microsoft.FastGelu)."""
     B, C, H, W = x.shape
     r = x
     h = group_norm(x, w, p + ".norm", groups, 1e-6)
@@ -121,7 +122,7 @@ def transformer(x: T, ctx: T, w, p: str, heads: int, groups: int, linear_proj: b
     h = h + attention(ln(h, "norm2"), ctx, w, b + ".attn2", heads)
     y = linear(ln(h, "norm3"), w, b + ".ff.net.0.proj")
     a, g = y.chunk(2, dim=-1)
-    h = h + linear(a * F.gelu(g), w, b + ".ff.net.2")
+    h = h + linear(a * F.gelu(g, approximate=gelu_approximate), w, b + ".ff.net.2")
     if not linear_proj:
         h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = conv(h, w, p + ".proj_out", padding=0)
@@ -153,7 +154,7 @@ def unet_forward(w: Dict[str, T], cfg: dict, sample: T, timestep, ehs: T, taps: 
         for j in range(lpb):
             h = resnet(h, emb, w, f"down_blocks.{i}.resnets.{j}", groups, eps)
             if cfg["down_attn"][i]:
-                h = transformer(h, ehs, w, f"down_blocks.{i}.attentions.{j}", heads_for(cfg, i), groups, lin)
+                h = transformer(h, ehs, w, f"down_blocks.{i}.attentions.{j}", heads_for(cfg, i), groups, lin, cfg.get("gelu_approximate", "none"))
             skips.append(h)
         if i < len(boc) - 1:
             h = conv(h, w, f"down_blocks.{i}.downsamplers.0.conv", stride=2, padding=1)
@@ -161,7 +162,7 @@ def unet_forward(w: Dict[str, T], cfg: dict, sample: T, timestep, ehs: T, taps: 
     if taps is not None:
         taps["down"] = h.clone()
     h = resnet(h, emb, w, "mid_block.resnets.0", groups, eps)
-    h = transformer(h, ehs, w, "mid_block.attentions.0", heads_for(cfg, len(boc) - 1), groups, lin)
+    h = transformer(h, ehs, w, "mid_block.attentions.0", heads_for(cfg, len(boc) - 1), groups, lin, cfg.get("gelu_approximate", "none"))
     h = resnet(h, emb, w, "mid_block.resnets.1", groups, eps)
     if taps is not None:
         taps["mid"] = h.clone()
@@ -171,7 +172,7 @@ def unet_forward(w: Dict[str, T], cfg: dict, sample: T, timestep, ehs: T, taps: 
             s = skips.pop()
             h = resnet(torch.cat([h, s], dim=1), emb, w, f"up_blocks.{i}.resnets.{j}", groups, eps)
             if up_attn[i]:
-                h = transformer(h, ehs, w, f"up_blocks.{i}.attentions.{j}", heads_for(cfg, len(boc) - 1 - i), groups, lin)
+                h = transformer(h, ehs, w, f"up_blocks.{i}.attentions.{j}", heads_for(cfg, len(boc) - 1 - i), groups, lin, cfg.get("gelu_approximate", "none"))
         if i < len(boc) - 1:
             # nearest 2x unless the skip connection dictates another size (forward_upsample_size)
             tgt = skips[-1].shape[-2:]

@@ -62,3 +62,37 @@ def test_oracle_vae_matches_reference_fixture_graph():
     tw = {k: torch.from_numpy(v) for k, v in w.items()}
     got = unet_ref.vae_decode(tw, cfg, torch.from_numpy(g["latent"])).numpy()
     assert np.abs(got - g["sample"]).max() < 2e-5
+
+
+def test_fused_dialect_writer_follows_the_optimizer_packing(tmp_path):
+    """modelgen's fused dialect restates scripts/_optimizer/fusion_attention_unet.py:215-226 (Attention weight = np.stack((q,k,v),
+    axis=1)), :231-280 (MatMul_KV = per-head interleave, Reshape [0,0,n,2,h]) and fusion_group_norm.py:108-160 (gamma/beta
+    initializers named after the node).  Read the file back with the independent oracle reader and undo the packing."""
+    import numpy as np
+    from diffusers_amd import modelgen
+    from oracle import onnx_io
+    ucfg = modelgen.unet_config(block_out_channels=(64, 128), layers_per_block=1, down_attn=(True, False), cross_attention_dim=64, num_heads=4)
+    w = modelgen.random_weights(modelgen.unet_param_shapes(ucfg), 3)
+    path = str(tmp_path / "unet.onnx")
+    modelgen.write_unet_onnx(path, ucfg, w, fused=True, approximate_gelu=True)
+    m = onnx_io.load(path)
+    ops = [n.op_type for n in m.nodes]
+    assert "InstanceNormalization" not in ops and "Softmax" not in ops and "Erf" not in ops
+    assert {"Attention", "MultiHeadAttention", "GroupNorm", "LayerNormalization", "FastGelu"} <= set(ops)
+    att = [n for n in m.nodes if n.op_type == "Attention"][0]
+    assert att.domain == "com.microsoft" and att.attr_i("num_heads") == 4
+    p = "down_blocks.0.attentions.0.transformer_blocks.0"
+    W = m.weight(att.inputs[1])
+    C = W.shape[0]
+    for j, t in enumerate("qkv"):
+        assert np.array_equal(W[:, j * C:(j + 1) * C], w[f"{p}.attn1.to_{t}.weight"].T)
+    kv = [n for n in m.nodes if n.name.startswith("MatMul_KV")][0]
+    Wkv = m.weight(kv.inputs[1])
+    heads, two, d = m.weight(kv.name + "_reshape_shape")[2:]
+    assert (heads, two, d) == (4, 2, 16)
+    Wkv = Wkv.reshape(Wkv.shape[0], heads, 2, d)
+    assert np.array_equal(Wkv[:, :, 0, :].reshape(-1, heads * d), w[f"{p}.attn2.to_k.weight"].T)
+    assert np.array_equal(Wkv[:, :, 1, :].reshape(-1, heads * d), w[f"{p}.attn2.to_v.weight"].T)
+    gn = [n for n in m.nodes if n.op_type == "GroupNorm"][0]
+    assert gn.inputs[1] == gn.name + "_gamma" and gn.attr_i("activation") == 1 and gn.attr_i("groups") == 32
+    assert np.array_equal(m.weight(gn.inputs[1]), w["down_blocks.0.resnets.0.norm1.weight"])
