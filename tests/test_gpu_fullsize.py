@@ -94,3 +94,35 @@ def test_sd15_batch_invariance_and_determinism(sd15):
     assert np.array_equal(full, again)
     part = pipe.unet(x[1:3], 500.0, ehs[1:3])
     assert rel_l2(part, full[1:3]) < 2e-3   # tile shapes change with the batch, so fp32 summation order may differ
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE configs[3] at full size
+SD21_DIR = os.environ.get("SDE_SD21_MODEL_DIR", "/tmp/sde_cfg_sd21_f16")
+
+
+def test_sd21_fullsize_unet_forward_768():
+    """SD v2.1 geometry at 768x768 (96x96 latents, 9,216 tokens at the top level; heads 5/10/20/20 of d=64; Linear proj_in/out;
+    cross_attention_dim 1024): one UNet forward, fp16 engine vs fp32 CPU oracle on the same synthetic weights."""
+    from diffusers_amd import modelgen
+    from diffusers_amd.pipeline import StableDiffusionPipeline
+    from oracle import model_dir, unet_ref
+    if not os.path.exists(os.path.join(SD21_DIR, ".complete")):
+        modelgen.write_model_dir(SD21_DIR, modelgen.sd21_unet_config(), modelgen.vae_config(), seed=42, dtype=np.float16)
+        open(os.path.join(SD21_DIR, ".complete"), "w").write("ok")
+    pipe = StableDiffusionPipeline(SD21_DIR)
+    try:
+        mi = pipe.info()
+        assert mi.use_linear_projection and mi.cross_attention_dim == 1024 and list(mi.num_heads[:4]) == [5, 10, 20, 20]
+        uw, ucfg = model_dir.load_unet(SD21_DIR)
+        uw = {k: torch.from_numpy(v) for k, v in uw.items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        rng = np.random.default_rng(2121)
+        x = rng.standard_normal((1, 4, 96, 96)).astype(np.float32)
+        ehs = (rng.standard_normal((1, 77, 1024)) * 0.5).astype(np.float32)
+        with torch.no_grad():
+            ref = unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), 733.0, torch.from_numpy(ehs)).numpy()
+        got = pipe.unet(x, 733.0, ehs)
+        assert np.isfinite(got).all()
+        assert rel_l2(got, ref) < 1e-2, rel_l2(got, ref)
+    finally:
+        pipe.close()
