@@ -41,6 +41,85 @@ constexpr int sched_slot(int k, int n) { return (k + 1) * 20 / (n + 1) - 1; }   
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 }  // namespace
 
+// epilogue shared by both kernels: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
+__device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT][MT], int m0, int n0, int ks, int z,
+                                             int wid, int wr, int wc, int lane, int fr, int fg)
+{
+    // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
+    const long long zD = z * p.sD, zR = z * p.sR;
+    if (p.splitk > 1) {
+        float* ws = p.ws + (long long)ks * p.M * p.Npad;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m0 + wr * 64 + mt * 16 + fr;
+            if (m < p.M) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = n0 + wc * WN + nt * 16 + 4 * fg;
+                    *(floatx4*)(ws + (long long)m * p.Npad + n) = acc[nt][mt];
+                }
+            }
+        }
+        return;
+    }
+    // EPI_STD through the wave's own LDS slice (see gemm_big.hip): fp32 staging, 16-byte row-order stores
+    char* const wlds = smem + wid * (SMEM_BYTES / 8);
+    const bool vec_ok = (p.ldd & 7) == 0;
+    constexpr int PITCH = WN * 4 + 32, CH = WN / 8, NI = 32 * CH / 64;
+    float bv[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + wc * WN + nt * 16 + 4 * fg;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
+    }
+    const half_t* R = p.R ? p.R + zR : nullptr;
+    half_t* D = p.D + zD;
+    const bool rvec_ok = R && (p.ldr & 7) == 0;
+#pragma unroll
+    for (int ms = 0; ms < 2; ++ms) {
+        half8 rr[NI];
+        if (R) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
+                const int m = min(m0 + wr * 64 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
+                if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
+                else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
+            }
+        }
+#pragma unroll
+        for (int mq = 0; mq < 2; ++mq) {
+            const int mt = ms * 2 + mq;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                floatx4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
+                *(floatx4*)(wlds + (mq * 16 + fr) * PITCH + (nt * 16 + 4 * fg) * 4) = o;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
+            const int m = m0 + wr * 64 + ms * 32 + row, n = n0 + wc * WN + ch * 8;
+            const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
+            const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            half8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (half_t)(R ? f[e] + (float)rr[i][e] : f[e]);
+            if (m < p.M && n < p.N) {
+                if (vec_ok && n + 8 <= p.N) *(half8*)(D + (long long)m * p.ldd + n) = v;
+                else for (int e = 0; e < 8 && n + e < p.N; ++e) D[(long long)m * p.ldd + n + e] = v[e];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // staging parts of one K-tile: 0-3 = A rows 64j..64j+63, 4-5 = W rows 0-63 / 64-127, 6 = W rows 128-159 (waves 0-3 only)
 template <bool CONV, bool UPS, int VAR>
 __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
@@ -253,79 +332,192 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
 #undef WAIT_PROLOGUE
 #undef ISSUE_L
 
-    // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
-    const long long zD = z * p.sD, zR = z * p.sR;
-    if (p.splitk > 1) {
-        float* ws = p.ws + (long long)ks * p.M * p.Npad;
+    mid_epilogue(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
+}
+
+// ------------------------------------------------------------------------------------------ loader-wave variant
+// 12 waves: waves 0-7 compute exactly as above but never touch global memory; waves 8-11 (one per SIMD, the kernel fits three
+// waves per SIMD at <= 168 VGPRs) do nothing but issue the LDS-DMA.  A `buffer_load ... lds` costs its issuing wave ~100-150
+// cycles; in the 8-wave kernel that cost sits in the compute waves' load sections and makes them longer than the MFMA sections
+// they are paired with (section stamps).  Here the compute waves' load sections are nine ds_read_b128 only.
+// All 12 waves execute the same barrier sequence; the loaders follow the timeline of waves 0-3.  Per K-tile (4 intervals):
+//   I0: A rows 0-127 of tile t+2 (rows only waves 0-3 read: their reads of tile t-1 are long done)     4 pieces per loader
+//   I1: A rows 128-255 (waves 4-7 finished reading tile t-1 during I0)                                  4
+//   I2: W rows, first 3 pieces                                                                          3
+//   I3: W rows, last 2 pieces; then wait until only tile t+2's 13 pieces are in flight (tile t+1 has landed)
+template <bool CONV, bool UPS>
+__global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int z = blockIdx.z;
+
+    const int nwg = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = p.colmajor ? bid % p.nbm : bid / p.nbn, tn = p.colmajor ? bid / p.nbm : bid - (bid / p.nbn) * p.nbn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk_all = p.K >> 6;
+    const int ks = blockIdx.y;
+    const int kt0 = (int)((long long)nk_all * ks / p.splitk);
+    const int nk = (int)((long long)nk_all * (ks + 1) / p.splitk) - kt0;
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define BAR() do { FENCE(); __builtin_amdgcn_s_barrier(); FENCE(); } while (0)
+
+    if (wid >= 8) {
+        // ================================================================ loader waves
+        const int lw = wid - 8;
+        const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A0 + z * p.sA), 0, OOB, RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((p.A1 ? p.A1 : p.A0) + z * p.sA), 0, OOB, RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + z * p.sW), 0, OOB, RSRC_FLAGS);
+        const int srow = lane >> 3;
+        const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
+        // A piece q = 2*j + i (j = 64-row part, i = 0/1): rows j*64 + (lw*2 + i)*8 + srow
+        unsigned a_off0[8], a_off1[8], a_mask[8];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + wr * 64 + mt * 16 + fr;
-            if (m < p.M) {
+        for (int q = 0; q < 8; ++q) {
+            const int m = m0 + (q >> 1) * 64 + (lw * 2 + (q & 1)) * 8 + srow;
+            const bool ok = m < p.M;
+            int pix = m;
+            if (CONV) {
+                const int hw = p.Ho * p.Wo;
+                const int nb = m / hw, rem = m - nb * hw;
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int cy = oy * p.stride, cx = ox * p.stride;
+                unsigned mask = 0;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int n = n0 + wc * WN + nt * 16 + 4 * fg;
-                    *(floatx4*)(ws + (long long)m * p.Npad + n) = acc[nt][mt];
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+                    if (ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) mask |= 1u << t;
                 }
+                mask |= (unsigned)(cy & 1) << 9 | (unsigned)(cx & 1) << 10;
+                a_mask[q] = mask;
+                pix = nb * p.Hs * p.Ws + (cy >> (UPS ? 1 : 0)) * p.Ws + (cx >> (UPS ? 1 : 0));
+            } else {
+                a_mask[q] = ok ? 1u : 0u;
             }
+            a_off0[q] = (unsigned)pix * (unsigned)(p.lda0 * 2) + lchunk16;
+            a_off1[q] = (unsigned)pix * (unsigned)(p.lda1 * 2) + lchunk16;
         }
+        // W piece i (0..4): rows (lw*5 + i)*8 + srow
+        const unsigned w_off = (unsigned)((n0 + lw * 40 + srow) * p.K) * 2u + lchunk16;
+        const int w_step = 8 * p.K * 2;
+
+        int st_k0 = kt0 << 6, st_tap = 0, st_c = st_k0;
+        if (CONV) { st_tap = kt0 % 9; st_c = (kt0 / 9) << 6; }
+        bool st_second = false;
+        unsigned st_bit = 1u;
+        int st_add = 0, st_ld2 = 0, st_ey0 = 0, st_ey1 = 0, st_ex0 = 0, st_ex1 = 0;
+        auto stage_scalars = [&]() {
+            st_second = st_c >= p.C0;
+            const int ld2 = (st_second ? p.lda1 : p.lda0) * 2;
+            st_add = (st_second ? st_c - p.C0 : st_c) * 2;
+            if (CONV) {
+                const int dy = st_tap / 3, dx = st_tap - dy * 3;
+                st_bit = 1u << st_tap;
+                if (UPS) { st_ld2 = ld2; st_ey0 = -(dy == 0); st_ey1 = (dy == 2); st_ex0 = -(dx == 0); st_ex1 = (dx == 2); }
+                else st_add += ((dy - 1) * p.Ws + (dx - 1)) * ld2;
+            }
+        };
+        stage_scalars();
+        auto stage_advance = [&]() {
+            st_k0 += 64;
+            if (CONV) { if (++st_tap == 9) { st_tap = 0; st_c += 64; } }
+            else st_c += 64;
+            stage_scalars();
+        };
+        auto issue_a = [&](int q, int buf) {
+            char* dst = smem + buf * STAGE + (q >> 1) * 8192 + (lw * 2 + (q & 1)) * 1024;
+            unsigned voff = (st_second ? a_off1[q] : a_off0[q]) + (unsigned)st_add;
+            if (CONV && UPS) {
+                const int ey = (a_mask[q] >> 9) & 1 ? st_ey1 : st_ey0;
+                const int ex = (a_mask[q] >> 10) & 1 ? st_ex1 : st_ex0;
+                voff += (unsigned)(__mul24(__mul24(ey, p.Ws) + ex, st_ld2));
+            }
+            voff = (a_mask[q] & st_bit) ? voff : OOB;
+            if (st_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, LDS_PTR(dst), 16, voff, 0, 0, 0);
+            else           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
+        };
+        auto issue_w = [&](int i, int buf) {
+            char* dst = smem + buf * STAGE + A_BYTES + (lw * 5 + i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, i * w_step + st_k0 * 2, 0, 0);
+        };
+        auto issue_all = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) issue_a(q, buf);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) issue_w(i, buf);
+        };
+        issue_all(0);
+        stage_advance();
+        if (nk > 1) { issue_all(1); stage_advance(); wait_vmcnt<13>(); }
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        int cb = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const int nb_ = cb == 0 ? 2 : cb - 1;          // slot of tile kt+2 == slot of tile kt-1
+            const bool more2 = kt + 2 < nk;
+            if (more2) { issue_a(0, nb_); issue_a(1, nb_); issue_a(2, nb_); issue_a(3, nb_); }
+            BAR();
+            if (more2) { issue_a(4, nb_); issue_a(5, nb_); issue_a(6, nb_); issue_a(7, nb_); }
+            BAR();
+            if (more2) { issue_w(0, nb_); issue_w(1, nb_); issue_w(2, nb_); }
+            BAR();
+            if (more2) { issue_w(3, nb_); issue_w(4, nb_); stage_advance(); wait_vmcnt<13>(); }
+            else wait_vmcnt<0>();
+            BAR();
+            cb = cb == 2 ? 0 : cb + 1;
+        }
+        __builtin_amdgcn_s_barrier();   // the extra barrier of waves 4-7
         return;
     }
-    // EPI_STD through the wave's own LDS slice (see gemm_big.hip): fp32 staging, 16-byte row-order stores
-    char* const wlds = smem + wid * (SMEM_BYTES / 8);
-    const bool vec_ok = (p.ldd & 7) == 0;
-    constexpr int PITCH = WN * 4 + 32, CH = WN / 8, NI = 32 * CH / 64;
-    float bv[NT][4];
+
+    // ==================================================================== compute waves
+    const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int swz0 = ((fg) ^ (fr & 7)) << 4, swz1 = ((4 + fg) ^ (fr & 7)) << 4;
+    const int a_rd0 = (wr * 64 + fr) * 128 + swz0, a_rd1 = (wr * 64 + fr) * 128 + swz1;
+    const int b_rd0 = A_BYTES + (wc * WN + fr) * 128 + swz0, b_rd1 = A_BYTES + (wc * WN + fr) * 128 + swz1;
+    floatx4 acc[NT][MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wc * WN + nt * 16 + 4 * fg;
+    for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
+        for (int b = 0; b < MT; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 bf[NT], af[MT];
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+#define LOAD_FRAGS(bo, ao)                                                                            \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(cur + (bo) + nt * 2048);  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) af[mt] = *(const half8*)(cur + (ao) + mt * 2048);
+#define MFMA_ALL()                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[nt][mt], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+    int cb = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* cur = smem + cb * STAGE;
+        LOAD_FRAGS(b_rd0, a_rd0)
+        BAR();
+        MFMA_ALL()
+        BAR();
+        LOAD_FRAGS(b_rd1, a_rd1)
+        BAR();
+        MFMA_ALL()
+        BAR();
+        cb = cb == 2 ? 0 : cb + 1;
     }
-    const half_t* R = p.R ? p.R + zR : nullptr;
-    half_t* D = p.D + zD;
-    const bool rvec_ok = R && (p.ldr & 7) == 0;
-#pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
-        half8 rr[NI];
-        if (R) {
-#pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
-                const int m = min(m0 + wr * 64 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
-                if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
-                else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
-            }
-        }
-#pragma unroll
-        for (int mq = 0; mq < 2; ++mq) {
-            const int mt = ms * 2 + mq;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                floatx4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
-                *(floatx4*)(wlds + (mq * 16 + fr) * PITCH + (nt * 16 + 4 * fg) * 4) = o;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
-            const int m = m0 + wr * 64 + ms * 32 + row, n = n0 + wc * WN + ch * 8;
-            const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
-            const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            half8 v;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)(R ? f[e] + (float)rr[i][e] : f[e]);
-            if (m < p.M && n < p.N) {
-                if (vec_ok && n + 8 <= p.N) *(half8*)(D + (long long)m * p.ldd + n) = v;
-                else for (int e = 0; e < 8 && n + e < p.N; ++e) D[(long long)m * p.ldd + n + e] = v[e];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7
+#undef LOAD_FRAGS
+#undef MFMA_ALL
+#undef BAR
+#undef FENCE
+    mid_epilogue(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -351,11 +543,31 @@ static void launch_mid_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
     hipLaunchKernelGGL(kern, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
 }
 
+template <bool CONV, bool UPS>
+static void launch_midl_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
+{
+    static bool attr_set = false;
+    auto kern = gemm_midl_kernel<CONV, UPS>;
+    if (!attr_set) {
+        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(768), SMEM_BYTES, ctx.stream, p);
+}
+
 void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)
 {
     p.nbm = cdiv(p.M, BM);
     p.nbn = p.Npad / BN;
     dim3 grid(p.nbm * p.nbn, p.splitk, batch);
+    // loader waves: +14-17 % on the 3x3 convolutions (long K); the short-K linears lose 2-5 % to the heavier prologue
+    static const int ldw = getenv("SDE_MIDLDW") ? atoi(getenv("SDE_MIDLDW")) : 1;   // tuning hook: 0 never, 1 convolutions, 2 always
+    if (ldw == 2 || (ldw == 1 && conv)) {
+        if (conv && p.ups) launch_midl_t<true, true>(ctx, p, grid);
+        else if (conv)     launch_midl_t<true, false>(ctx, p, grid);
+        else               launch_midl_t<false, false>(ctx, p, grid);
+        return;
+    }
 #ifdef SDE_DIAG
     // schedule experiments (diagnostic builds): SDE_MIDVAR=1..3 selects kMidSched[v] for plain 3x3 convs
     static const int var = getenv("SDE_MIDVAR") ? atoi(getenv("SDE_MIDVAR")) : 0;
