@@ -92,6 +92,9 @@ SYMBOLS = {
     "sde_scheduler_add_noise": (_i, [_vp, _vp, _vp, C.c_size_t, _f, _vp]),
     "sde_txt2img_opts_default": (None, [C.POINTER(Txt2ImgOpts)]),
     "sde_txt2img_run": (_i, [_vp, _vp, C.POINTER(Txt2ImgOpts), _vp, C.POINTER(RunStats)]),
+    "sde_rng_standard_normal": (_i, [C.c_uint64, C.c_uint64, _vp, C.c_size_t]),
+    "sde_rng_chacha_words": (_i, [_vp, _i, _vp, C.c_size_t]),
+    "sde_rng_seed_key": (_i, [C.c_uint64, _vp]),
     "sde_profile_enable": (_i, [_vp, _i]),
     "sde_profile_reset": (_i, [_vp]),
     "sde_profile_get": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),

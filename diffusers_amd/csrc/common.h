@@ -35,6 +35,28 @@ struct SdeError : std::runtime_error {
 
 void sde_set_last_error(const std::string& m);
 
+// every C ABI entry point runs inside this: nothing is thrown across the boundary
+template <typename F>
+static inline sde_status guarded(F&& f)
+{
+    try {
+        f();
+        return SDE_OK;
+    } catch (const SdeError& e) {
+        sde_set_last_error(e.what());
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        sde_set_last_error("out of host memory");
+        return SDE_ERR_DEVICE;
+    } catch (const std::exception& e) {
+        sde_set_last_error(e.what());
+        return SDE_ERR_INVALID_ARGUMENT;
+    } catch (...) {
+        sde_set_last_error("unknown error");
+        return SDE_ERR_INVALID_ARGUMENT;
+    }
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }

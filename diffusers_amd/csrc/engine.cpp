@@ -8,32 +8,12 @@
 #include <random>
 
 #include "model.h"
+#include "rng.h"
 #include "scheduler.h"
 
 // ------------------------------------------------------------------------------------------ errors
 static thread_local std::string g_last_error;
 void sde_set_last_error(const std::string& m) { g_last_error = m; }
-
-template <typename F>
-static sde_status guarded(F&& f)
-{
-    try {
-        f();
-        return SDE_OK;
-    } catch (const SdeError& e) {
-        g_last_error = e.what();
-        return e.code;
-    } catch (const std::bad_alloc&) {
-        g_last_error = "out of host memory";
-        return SDE_ERR_DEVICE;
-    } catch (const std::exception& e) {
-        g_last_error = e.what();
-        return SDE_ERR_INVALID_ARGUMENT;
-    } catch (...) {
-        g_last_error = "unknown error";
-        return SDE_ERR_INVALID_ARGUMENT;
-    }
-}
 
 // ------------------------------------------------------------------------------------------ profiler
 struct Profiler {
@@ -555,11 +535,6 @@ void sde_txt2img_opts_default(sde_txt2img_opts* o)
     o->callback_frequency = 1;
 }
 
-static void fill_normal(std::mt19937_64& rng, float* dst, size_t n)
-{
-    std::normal_distribution<float> nd(0.f, 1.f);
-    for (size_t i = 0; i < n; ++i) dst[i] = nd(rng);
-}
 
 sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_opts* o, float* images_out, sde_run_stats* stats)
 {
@@ -589,7 +564,8 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         hipStream_t st = e->stream;
 
         const uint64_t seed = o->has_seed ? o->seed : std::random_device{}();
-        std::mt19937_64 rng(seed), sched_rng(seed + 31337);  // :249,267 (engine RNG streams; not rand::StdRng-compatible)
+        // :249,267 -- StdRng::seed_from_u64(seed) / (seed + 31337), restated in rng.h (u64 add wraps in release builds)
+        sde::ChaChaRng rng = sde::ChaChaRng::seed_from_u64(seed), sched_rng = sde::ChaChaRng::seed_from_u64(seed + 31337);
 
         sch->set_timesteps(o->steps);                         // :264
         const std::vector<float> ts = sch->timesteps;         // :269
@@ -618,7 +594,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             HIP_CHECK(hipMemcpyAsync(d_lat, o->init_latents, per * 4, o->buffers_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         } else {
             host_tmp.resize(per);
-            fill_normal(rng, host_tmp.data(), per);           // :261-262
+            sde::fill_standard_normal(rng, host_tmp.data(), per);           // :261-262
             HIP_CHECK(hipMemcpyAsync(d_lat, host_tmp.data(), per * 4, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipStreamSynchronize(st));
         }
@@ -664,7 +640,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
                 else {
                     const float* src;
                     if (o->step_noise) src = o->step_noise + (size_t)i * per;
-                    else { host_tmp.resize(per); fill_normal(sched_rng, host_tmp.data(), per); src = host_tmp.data(); }
+                    else { host_tmp.resize(per); sde::fill_standard_normal(sched_rng, host_tmp.data(), per); src = host_tmp.data(); }
                     HIP_CHECK(hipMemcpyAsync(e->noise.p, src, per * 4, hipMemcpyHostToDevice, st));
                     HIP_CHECK(hipStreamSynchronize(st));
                     a.noise = e->noise.as<float>();

@@ -165,7 +165,7 @@ typedef struct sde_txt2img_opts {
     float guidance_scale;       /* CFG is on iff > 1.0 (:258) */
     int has_rescale_cfg; float rescale_cfg; /* Option<f32> (:293-297) */
     int steps;
-    int has_seed; uint64_t seed; /* None -> random (:248).  See DESIGN.md: RNG stream is NOT rand::StdRng-compatible. */
+    int has_seed; uint64_t seed; /* None -> random (:248).  Latents come from StdRng::seed_from_u64(seed), scheduler noise from seed + 31337 (:249,267); see sde_rng_standard_normal. */
     int batch_size;             /* B = positive_prompt.len() (:256) */
     /* text embeddings from `encode_prompt` (impl_main.rs:339-375): f32 [N,S,D], N = 2B (uncond FIRST) when CFG is on, else B */
     const float* ehs; int S, D;
@@ -196,6 +196,19 @@ typedef struct sde_run_stats {
  * leaves it in.  images_out: f32 [B,H,W,3] in [0,1]. */
 sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* scheduler, const sde_txt2img_opts* opts,
                            float* images_out, sde_run_stats* stats);
+
+/* Seeded draws (host code; no device needed) --------------------------------------------------
+ * What `Array::<f32>::random_using(shape, StandardNormal, &mut StdRng::seed_from_u64(seed))` yields in the reference
+ * (impl_txt2img.rs:248-249,261-262,267; euler_ancestral_discrete.rs:203; ddpm.rs:224): ChaCha12 keyed by rand_core's
+ * PCG32 seed expansion, 256-layer Ziggurat on f64, cast to f32, row-major.  `skip` samples are drawn and dropped first
+ * (the scheduler stream after k steps of B*4*h*w draws).  The crates that define this (rand 0.8, rand_chacha 0.3,
+ * rand_distr 0.4 via ndarray-rand 0.14, Cargo.toml:23) are not vendored by the reference and no known-answer stream of
+ * theirs is available here: parity with the Rust stream is unpinned above the ChaCha core. */
+sde_status sde_rng_standard_normal(uint64_t seed, uint64_t skip, float* out, size_t n);
+/* The raw generator under it, for known-answer tests: `n_words` u32 outputs of ChaCha with `rounds` rounds (StdRng: 12)
+ * under `key`, block counter and stream id starting at 0; and the key `seed_from_u64(seed)` derives. */
+sde_status sde_rng_chacha_words(const uint8_t key[32], int rounds, uint32_t* out, size_t n_words);
+sde_status sde_rng_seed_key(uint64_t seed, uint8_t key_out[32]);
 
 /* Measurement hooks (bench.py) ------------------------------------------------------------- */
 typedef struct sde_kernel_stat {

@@ -174,6 +174,35 @@ def test_seeded_runs_are_reproducible(pipe):
     assert np.array_equal(a, b) and not np.array_equal(a, c)
 
 
+@pytest.mark.parametrize("kind", ["euler_a", "ddpm", "euler"])
+def test_seeded_run_draws_the_reference_streams(pipe, kind):
+    """`seed` alone must give what the reference's two StdRng streams give (impl_txt2img.rs:249,262,267): the same run with
+    the ORACLE's draws injected (latents from seed, per-step scheduler noise from seed + 31337, consumed step after step)
+    ends bit-identical.  Euler draws and discards a tensor per step in the reference; nothing depends on it."""
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionTxt2ImgOptions
+    from oracle import rng as R
+    B, h, w, steps, seed = 2, 16, 16, 4, 1234
+    ehs = (np.random.default_rng(3).standard_normal((2 * B, 77, 64)) * 0.5).astype(np.float32)
+    sch = N.BY_NAME[kind].stable_diffusion_v1_optimized_default()
+    seeded = StableDiffusionTxt2ImgOptions(height=h * 8, width=w * 8, steps=steps, text_embeddings=ehs, batch_size=B,
+                                           seed=seed).run(pipe, sch, trace=True)
+    init = R.random_using((B, 4, h, w), R.StdRng.seed_from_u64(seed))
+    srng = R.StdRng.seed_from_u64(seed + 31337)
+    nt = seeded.unet_calls
+    noise = np.zeros((nt, B, 4, h, w), np.float32)
+    for i in range(nt):
+        # ddpm.rs:189-193,223: no draw when the POSITION of t in `timesteps` is 0, i.e. on the first step (REFERENCE_QUIRK);
+        # euler_ancestral_discrete.rs:203: a draw on every step
+        if kind == "euler_a" or (kind == "ddpm" and i > 0):
+            noise[i] = R.random_using((B, 4, h, w), srng)
+    sch2 = N.BY_NAME[kind].stable_diffusion_v1_optimized_default()
+    injected = StableDiffusionTxt2ImgOptions(height=h * 8, width=w * 8, steps=steps, text_embeddings=ehs, batch_size=B,
+                                             init_latents=init, step_noise=noise).run(pipe, sch2, trace=True)
+    assert np.array_equal(seeded.final_latents, injected.final_latents)
+    assert np.array_equal(seeded.noise_pred[0], injected.noise_pred[0])
+
+
 @pytest.mark.parametrize("kind,rescale", [("euler_a", None), ("dpmpp", 0.7)])
 def test_cfg_pair_split_matches_single_engine(tiny_model_dir, pipe, kind, rescale):
     """SURVEY 8e / BASELINE config 3: two engines each run one half of the CFG batch and swap halves once per step through

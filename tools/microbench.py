@@ -7,6 +7,7 @@ from diffusers_amd import _lib, modelgen
 from diffusers_amd.pipeline import StableDiffusionPipeline
 
 NB = int(os.environ.get("NB", "16"))
+KERN = int(os.environ.get("MB_KERNEL", "0"))   # 0 heuristic, 2 / 3 force the 256x320 / 256x160 kernel (with SDE_SPLITK=n)
 CONVS = [  # H, Cin, Cout, k, stride, ups
     (64, 320, 320, 3, 1, 0), (64, 640, 320, 3, 1, 0), (32, 640, 640, 3, 1, 0), (32, 1280, 640, 3, 1, 0), (16, 1280, 1280, 3, 1, 0),
     (16, 2560, 1280, 3, 1, 0), (8, 1280, 1280, 3, 1, 0), (8, 2560, 1280, 3, 1, 0), (32, 320, 320, 3, 1, 1), (64, 320, 320, 3, 2, 0),
@@ -36,10 +37,10 @@ def main():
         Hv = 2 * H if ups else H
         Ho = (Hv - 1) // stride + 1 if k == 3 else Hv
         out = np.empty((NB, Ho, Ho, Cout), np.float32)
-        _lib.check(L.sde_test_conv(p._h, 0, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
+        _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
         p.profile_reset(); p.profile(True)
         for _ in range(reps):
-            _lib.check(L.sde_test_conv(p._h, 0, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
+            _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
         st = [s for s in p.profile_get() if "mfma" in s["name"]]
         p.profile(False)
         for s in st:
