@@ -383,7 +383,9 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         const int tiles = cdiv(a.M, 256) * (a.Npad / 160) * a.batch, nk = a.K >> 6;
         int sk = 1;
         if (a.batch == 1 && ctx.splitk_ws && tiles < 192 && nk >= 64) {
-            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 32), 2);
+            // 16x16 level (128 tiles): 2 ways; 8x8 level (32 tiles, K = 11520 / 23040): 8 ways = one block per CU, 47.6 / 70.1 us
+            // against 54.7 / 94.4 us on the 4-wave kernel (MI355X, UNet batch 16)
+            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 16), tiles <= 32 ? 8 : 2);
             if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;
         }

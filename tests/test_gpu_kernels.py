@@ -113,7 +113,9 @@ MID_CASES = [
     (1, 16, 16, 192, 320, 3, 2, 0),     # stride 2
     (1, 12, 12, 128, 480, 3, 1, 1),     # fused nearest-2x upsample, three column tiles
     (1, 30, 30, 256, 320, 1, 1, 0),     # linear, ragged M, 4 K-tiles
-    (1, 8, 8, 1280, 640, 3, 1, 0),      # long K: split-K slabs through this kernel
+    (1, 8, 8, 1280, 640, 3, 1, 0),      # long K: split-K slabs through this kernel (8 ways: <= 32 tiles)
+    (16, 8, 8, 1280, 1280, 3, 1, 0),    # the 8x8 UNet level at UNet batch 16: 32 tiles x 8-way split-K = one block per CU
+    (16, 16, 16, 640, 320, 3, 2, 0),    # stride-2 downsample into 8x8, 90 K-tiles, 8-way split
     (1, 40, 40, 64, 160, 1, 1, 0),      # a single K-tile (prologue only)
     (1, 20, 20, 128, 320, 1, 1, 0),     # two K-tiles (prologue covers everything, loop issues nothing)
     (1, 20, 20, 192, 320, 1, 1, 0),     # three K-tiles (first use of the third ring slot)
