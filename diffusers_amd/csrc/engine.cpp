@@ -766,7 +766,8 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         engine_activate(e);
         LaunchCtx ctx = e->ctx; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3;   // 0 fast, 1 plain, 2 / 3 force the 256x320 / 256x160 kernel
         const int taps = ksize * ksize;
-        const int Hv = upsample ? 2 * Hi : Hi, Wv = upsample ? 2 * Wi : Wi;
+        // upsample: 1 = nearest 2x; 2 = 2x cropped to (2*Hi - 1) x (2*Wi - 1), the UNet's upsample-to-skip-size on odd latents
+        const int Hv = upsample ? 2 * Hi - (upsample == 2) : Hi, Wv = upsample ? 2 * Wi - (upsample == 2) : Wi;
         const int Ho = ksize == 3 ? (Hv - 1) / stride + 1 : Hv, Wo = ksize == 3 ? (Wv - 1) / stride + 1 : Wv;
         const size_t nx = (size_t)NB * Hi * Wi * Cin, nw = (size_t)Cout * Cin * taps, no = (size_t)NB * Ho * Wo * Cout;
         const int Npad = gemm_npad(Cout), K = taps * Cin;
@@ -782,7 +783,7 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         r.dst_row0 = 0; r.Ipad = Cin; r.i0 = 0; r.Kdst = K;
         launch_repack(ctx, r);
         GemmArgs g;
-        g.A0 = dxh.as<half_t>(); g.lda0 = Cin; g.C0 = Cin; g.taps = taps; g.stride = ksize == 3 ? stride : 1; g.ups = ksize == 3 ? upsample : 0;
+        g.A0 = dxh.as<half_t>(); g.lda0 = Cin; g.C0 = Cin; g.taps = taps; g.stride = ksize == 3 ? stride : 1; g.ups = ksize == 3 ? (upsample != 0) : 0;
         g.Hi = Hv; g.Wi = Wv; g.Ho = Ho; g.Wo = Wo; g.M = NB * Ho * Wo; g.N = Cout; g.K = K;
         g.W = dwh.as<half_t>(); g.Npad = Npad; g.bias = bias ? dbias.as<float>() : nullptr; g.D = doh.as<half_t>(); g.ldd = Cout;
         launch_gemm(ctx, g);

@@ -275,7 +275,7 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     p.A0 = a.A0; p.A1 = a.A1; p.C0 = a.C0; p.C1 = a.C1; p.lda0 = a.lda0; p.lda1 = a.lda1;
     p.M = a.M; p.N = a.N; p.K = a.K; p.taps = a.taps; p.stride = a.stride; p.ups = a.ups;
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
-    p.Hs = a.ups ? a.Hi / 2 : a.Hi; p.Ws = a.ups ? a.Wi / 2 : a.Wi;
+    p.Hs = a.ups ? (a.Hi + 1) / 2 : a.Hi; p.Ws = a.ups ? (a.Wi + 1) / 2 : a.Wi;   // ups: virtual (Hi x Wi) = nearest-2x of (Hs x Ws), cropped when odd
     p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
     p.epi = a.epi; p.gelu_tanh = a.gelu_tanh; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
     p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr; p.stamps = nullptr;
@@ -383,9 +383,10 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         const int tiles = cdiv(a.M, 256) * (a.Npad / 160) * a.batch, nk = a.K >> 6;
         int sk = 1;
         if (a.batch == 1 && ctx.splitk_ws && tiles < 192 && nk >= 64) {
-            // 16x16 level (128 tiles): 2 ways; 8x8 level (32 tiles, K = 11520 / 23040): 8 ways = one block per CU, 47.6 / 70.1 us
-            // against 54.7 / 94.4 us on the 4-wave kernel (MI355X, UNet batch 16)
-            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 16), tiles <= 32 ? 8 : 2);
+            // as many ways as fill one block per CU: 16x16 level (128 tiles) 2 ways; the 640-channel stride-2 downsample into 16x16
+            // (64 tiles) 4 ways; 8x8 level (32 tiles, K = 11520 / 23040) 8 ways: 47.6 / 70.1 us against 54.7 / 94.4 us on the
+            // 4-wave kernel (MI355X, UNet batch 16)
+            sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 16), 8);
             if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;
         }

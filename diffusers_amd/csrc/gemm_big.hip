@@ -394,7 +394,7 @@ bool gemm_big_supported(const GemmArgs& a)
     if (!gemm_big_bn(a) || (a.epi != EPI_STD && a.epi != EPI_GEGLU_PAIR) || (a.N & 3)) return false;   // other epilogues stay on gemm.hip's kernel
     if (a.epi == EPI_GEGLU_PAIR && (a.ldd & 1)) return false;
     // 32-bit byte offsets inside a 2 GiB descriptor window
-    const long long rowsA = a.taps == 9 ? (long long)(a.M / (a.Ho * a.Wo)) * (a.ups ? (a.Hi / 2) * (a.Wi / 2) : a.Hi * a.Wi) : a.M;
+    const long long rowsA = a.taps == 9 ? (long long)(a.M / (a.Ho * a.Wo)) * (a.ups ? ((a.Hi + 1) / 2) * ((a.Wi + 1) / 2) : a.Hi * a.Wi) : a.M;
     if (rowsA >= (1 << 24) || a.lda0 * 2 >= (1 << 23) || a.lda1 * 2 >= (1 << 23) || a.Wi >= (1 << 16)) return false;
     if (rowsA * std::max(a.lda0, a.lda1) * 2 >= 0x7ff00000LL) return false;
     if ((long long)a.Npad * a.K * 2 >= 0x7ff00000LL) return false;

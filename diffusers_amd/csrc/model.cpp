@@ -132,13 +132,17 @@ void linear(Exec& ex, const DevLinear& L, const half_t* A, int lda, int M, half_
 }
 
 // 3x3 conv (pad 1) over NHWC; returns output spatial size through Ho/Wo
+// ups: the source (H x W) is nearest-upsampled on the fly to (Hu x Wu); 0 = exactly 2x.  Hu = 2H - 1 / Wu = 2W - 1 is the
+// `forward_upsample_size` case of the exported UNet (F.interpolate(size = skip size), ONNX Resize asymmetric / floor): for those
+// sizes floor(y * H / Hu) == y >> 1 for every y < Hu, i.e. the 2x upsample cropped by one row / column.
 void conv3x3(Exec& ex, const DevLinear& L, const half_t* A, int C, int NB, int H, int W, int stride, int ups, half_t* D, int ldd,
-             const float* bias, const half_t* R, int ldr, int epi = EPI_STD, float* Df = nullptr)
+             const float* bias, const half_t* R, int ldr, int epi = EPI_STD, float* Df = nullptr, int Hu = 0, int Wu = 0)
 {
     GemmArgs g;
     g.A0 = A; g.lda0 = C; g.C0 = C;
     g.taps = 9; g.stride = stride; g.ups = ups;
-    g.Hi = ups ? 2 * H : H; g.Wi = ups ? 2 * W : W;
+    g.Hi = ups ? (Hu ? Hu : 2 * H) : H; g.Wi = ups ? (Wu ? Wu : 2 * W) : W;
+    SDE_REQUIRE(!ups || ((g.Hi + 1) / 2 == H && (g.Wi + 1) / 2 == W), SDE_ERR_INVALID_ARGUMENT, "conv3x3: upsample target must be 2x or 2x - 1");
     g.Ho = (g.Hi - 1) / stride + 1; g.Wo = (g.Wi - 1) / stride + 1;
     g.M = NB * g.Ho * g.Wo; g.N = L.N; g.K = L.K;
     g.W = L.W; g.Npad = L.Npad; g.bias = bias; g.R = R; g.ldr = ldr; g.D = D; g.Df = Df; g.ldd = ldd; g.epi = epi;
@@ -378,9 +382,7 @@ void UNetModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b, 
 void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, float timestep, const half_t* ehs_h, int S,
                         half_t* const* kv_cache, bool fill_kv, float* out_nchw) const
 {
-    const int div = 1 << (n_levels - 1);
-    SDE_REQUIRE(h % div == 0 && w % div == 0, SDE_ERR_INVALID_ARGUMENT,
-                "latent height/width must be divisible by " + std::to_string(div) + " (image size by " + std::to_string(8 * div) + ")");
+    SDE_REQUIRE(h > 0 && w > 0, SDE_ERR_INVALID_ARGUMENT, "empty latent");
     Arena& ar = *ex.arena;
     const float eps = 1e-5f;
     // 1. time embedding: timestep is cast to int64 inside the exported graph (sd2pyke.py:121) => truncation
@@ -437,9 +439,14 @@ void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, f
             if (!up[i].att.empty()) cur = transformer(ex, up[i].att[j], cur, N, H, W, kv_cache[up[i].att[j].kv_index], S);
         }
         if (up[i].has_up) {
-            half_t* u = ar.get<half_t>((size_t)N * 4 * H * W * C);
-            conv3x3(ex, up[i].up, cur, C, N, H, W, 1, 1, u, C, up[i].up.bias, nullptr, 0);
-            cur = u; H *= 2; W *= 2;
+            // The exporter traces the UNet on a 64 x 65 latent (sd2pyke.py:287-288) so that the graph upsamples to the SIZE of the
+            // next skip connection (diffusers' forward_upsample_size) instead of by 2: any latent size works, as the reference
+            // allows every image size divisible by 8 (impl_txt2img.rs:251-253).  Stride-2 convs round up, so that size is 2x or 2x - 1.
+            SDE_REQUIRE(!skips.empty(), SDE_ERR_MODEL, "unet: skip stack underflow");
+            const int Hu = skips.back().H, Wu = skips.back().W;
+            half_t* u = ar.get<half_t>((size_t)N * Hu * Wu * C);
+            conv3x3(ex, up[i].up, cur, C, N, H, W, 1, 1, u, C, up[i].up.bias, nullptr, 0, EPI_STD, nullptr, Hu, Wu);
+            cur = u; H = Hu; W = Wu;
         }
     }
     // 6. head

@@ -226,7 +226,9 @@ sde_status sde_profile_get(sde_engine* e, sde_kernel_stat* out, int capacity, in
 sde_status sde_synchronize(sde_engine* e);
 
 /* Kernel-level test hooks: run ONE contraction through the MFMA path (naive=0) or the plain path
- * (naive=1) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32. */
+ * (naive=1; 2 / 3 force the 256x320 / 256x160 kernels) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
+ * upsample: 0 none, 1 nearest 2x before the conv, 2 nearest to (2*Hi-1) x (2*Wi-1) (the exported UNet's upsample to its skip
+ * connection's size on odd latents). */
 sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin,
                          const float* w, const float* bias, int Cout, int ksize, int stride, int upsample,
                          float* out);

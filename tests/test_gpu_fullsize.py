@@ -62,6 +62,21 @@ def test_sd15_unet_forward(sd15, S, t):
     assert rel_l2(got, ref) < 1e-2, rel_l2(got, ref)
 
 
+def test_sd15_unet_forward_image_size_not_a_multiple_of_64(sd15):
+    """520 x 456 pixels = 65 x 57 latents -> 33 x 29 -> 17 x 15 -> 9 x 8: every stride-2 conv rounds up and every upsample
+    targets its skip connection's size (2x - 1 in one or both dimensions), as the exported graph does."""
+    from oracle import unet_ref
+    pipe, uw, ucfg, _, _ = sd15
+    rng = np.random.default_rng(65)
+    x = rng.standard_normal((2, 4, 65, 57)).astype(np.float32)
+    ehs = (rng.standard_normal((2, 77, 768)) * 0.5).astype(np.float32)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), 603.0, torch.from_numpy(ehs)).numpy()
+    got = pipe.unet(x, 603.0, ehs)
+    assert got.shape == ref.shape == (2, 4, 65, 57) and np.isfinite(got).all()
+    assert rel_l2(got, ref) < 1e-2, rel_l2(got, ref)
+
+
 def test_sd15_txt2img_three_steps_and_decode(sd15):
     from diffusers_amd import schedulers as N
     from diffusers_amd.pipeline import StableDiffusionTxt2ImgOptions

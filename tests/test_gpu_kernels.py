@@ -27,7 +27,7 @@ def run_conv(engine, naive, x, w, b, k, stride, ups):
     from diffusers_amd import _lib
     NB, Hi, Wi, Cin = x.shape
     Cout = w.shape[0]
-    Hv, Wv = (2 * Hi, 2 * Wi) if ups else (Hi, Wi)
+    Hv, Wv = (2 * Hi - (ups == 2), 2 * Wi - (ups == 2)) if ups else (Hi, Wi)
     Ho, Wo = ((Hv - 1) // stride + 1, (Wv - 1) // stride + 1) if k == 3 else (Hv, Wv)
     out = np.empty((NB, Ho, Wo, Cout), np.float32)
     _lib.check(_lib.lib().sde_test_conv(engine._h, naive, x.ctypes.data, NB, Hi, Wi, Cin, w.ctypes.data,
@@ -41,6 +41,7 @@ CONV_CASES = [
     (1, 32, 32, 320, 320, 3, 1, 0),     # BM=128, BN=160
     (2, 16, 16, 128, 128, 3, 2, 0),     # stride-2 downsample, BN=128
     (1, 8, 8, 128, 256, 3, 1, 1),       # fused nearest-2x upsample
+    (2, 9, 8, 128, 160, 3, 1, 2),       # fused upsample to 17 x 15 (skip-connection size on odd latents)
     (1, 13, 11, 64, 64, 3, 1, 0),       # ragged M (not a multiple of the tile), odd spatial size
     (1, 15, 9, 64, 64, 3, 2, 0),        # stride 2 on odd sizes
     (3, 8, 8, 192, 320, 1, 1, 0),       # 1x1 / linear
@@ -64,6 +65,9 @@ def test_conv_mfma_vs_plain_vs_torch(engine, case):
     xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
     if ups:
         xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+        if ups == 2:   # upsample to (2H-1, 2W-1): F.interpolate(size=...) nearest == the 2x result without its last row / column
+            assert torch.equal(xt[:, :, :-1, :-1], F.interpolate(xt[:, :, ::2, ::2], size=(xt.shape[2] - 1, xt.shape[3] - 1), mode="nearest"))
+            xt = xt[:, :, :-1, :-1]
     ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=stride if k == 3 else 1,
                    padding=1 if k == 3 else 0).permute(0, 2, 3, 1).numpy()
     assert fast.shape == ref.shape
@@ -84,6 +88,7 @@ BIG_CASES = [
     (1, 40, 40, 64, 320, 1, 1, 0),      # a single K-tile (prologue only)
     (1, 32, 32, 128, 256, 3, 1, 0),     # 256x256 tile variant (VAE widths)
     (1, 16, 16, 256, 512, 3, 1, 1),     # same, two column tiles, fused upsample
+    (1, 17, 15, 320, 320, 3, 1, 2),     # fused upsample to 33 x 29 (odd latents), 256x320 tile
     (2, 24, 24, 128, 256, 1, 1, 0),     # same, linear, ragged M
 ]
 
@@ -99,6 +104,9 @@ def test_conv_big_tile_kernel(engine, case):
     xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
     if ups:
         xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+        if ups == 2:   # upsample to (2H-1, 2W-1): F.interpolate(size=...) nearest == the 2x result without its last row / column
+            assert torch.equal(xt[:, :, :-1, :-1], F.interpolate(xt[:, :, ::2, ::2], size=(xt.shape[2] - 1, xt.shape[3] - 1), mode="nearest"))
+            xt = xt[:, :, :-1, :-1]
     ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=stride if k == 3 else 1,
                    padding=1 if k == 3 else 0).permute(0, 2, 3, 1).numpy()
     assert big.shape == ref.shape
@@ -112,10 +120,12 @@ MID_CASES = [
     (1, 24, 20, 64, 160, 3, 1, 0),      # ragged M tile (480 rows), 9 K-tiles
     (1, 16, 16, 192, 320, 3, 2, 0),     # stride 2
     (1, 12, 12, 128, 480, 3, 1, 1),     # fused nearest-2x upsample, three column tiles
+    (1, 9, 8, 128, 320, 3, 1, 2),       # fused upsample to 17 x 15 (odd latents)
     (1, 30, 30, 256, 320, 1, 1, 0),     # linear, ragged M, 4 K-tiles
     (1, 8, 8, 1280, 640, 3, 1, 0),      # long K: split-K slabs through this kernel (8 ways: <= 32 tiles)
     (16, 8, 8, 1280, 1280, 3, 1, 0),    # the 8x8 UNet level at UNet batch 16: 32 tiles x 8-way split-K = one block per CU
     (16, 16, 16, 640, 320, 3, 2, 0),    # stride-2 downsample into 8x8, 90 K-tiles, 8-way split
+    (16, 32, 32, 640, 640, 3, 2, 0),    # stride-2 downsample into 16x16 at UNet batch 16: 64 tiles x 4-way split
     (1, 40, 40, 64, 160, 1, 1, 0),      # a single K-tile (prologue only)
     (1, 20, 20, 128, 320, 1, 1, 0),     # two K-tiles (prologue covers everything, loop issues nothing)
     (1, 20, 20, 192, 320, 1, 1, 0),     # three K-tiles (first use of the third ring slot)
@@ -133,6 +143,9 @@ def test_conv_mid_tile_kernel(engine, case):
     xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
     if ups:
         xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+        if ups == 2:   # upsample to (2H-1, 2W-1): F.interpolate(size=...) nearest == the 2x result without its last row / column
+            assert torch.equal(xt[:, :, :-1, :-1], F.interpolate(xt[:, :, ::2, ::2], size=(xt.shape[2] - 1, xt.shape[3] - 1), mode="nearest"))
+            xt = xt[:, :, :-1, :-1]
     ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=stride if k == 3 else 1,
                    padding=1 if k == 3 else 0).permute(0, 2, 3, 1).numpy()
     assert mid.shape == ref.shape
