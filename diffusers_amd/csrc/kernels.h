@@ -101,7 +101,7 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a);
 void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows, int C, const float* gamma,
                       const float* beta, float eps);
 // in-place softmax over the last dim of a [rows][cols] fp16 matrix (fp32 math)
-void launch_softmax_rows(const LaunchCtx& ctx, half_t* X, int64_t rows, int cols);
+void launch_softmax_rows(const LaunchCtx& ctx, half_t* X, int64_t rows, int cols, int pitch);   // in place; columns [cols, pitch) become 0
 
 // ------------------------------------------------------------------------------------------ element-wise / edge kernels
 // NCHW f32 [NB,C,H,W] -> NHWC fp16 [NB*H*W][Cpad] (channels >= C zero), scaled

@@ -523,36 +523,37 @@ void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, in
             attention(ex, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, ao, C, B, 1, S, S, C);
         } else {
             // wide single head (C = 512): scores via batched GEMMs + row softmax (34 GFLOP / 512^2 image, 1.4 % of the decoder)
-            SDE_REQUIRE(S % 8 == 0, SDE_ERR_INVALID_ARGUMENT, "vae attention: h*w must be a multiple of 8");
-            const int Spad = gemm_npad(S);
+            // token counts that are not a multiple of 64 (image sizes that are not a multiple of 64): score rows and V^T rows are
+            // pitched to Sp with zero padding, so the P.V product still runs whole 64-wide K chunks
+            const int Spad = gemm_npad(S), Sp = round_up(S, 64);
             half_t* q = ar.get<half_t>((size_t)M * C);
             half_t* k = ar.get<half_t>((size_t)B * Spad * C);
-            half_t* vT = ar.get<half_t>((size_t)B * gemm_npad(C) * S);
-            half_t* sc = ar.get<half_t>((size_t)B * S * S);
+            half_t* vT = ar.get<half_t>((size_t)B * gemm_npad(C) * Sp);
+            half_t* sc = ar.get<half_t>((size_t)B * S * Sp);
             if (!ex.dry() && Spad != S) HIP_CHECK(hipMemsetAsync(k, 0, (size_t)B * Spad * C * sizeof(half_t), ex.ctx.stream));
-            if (!ex.dry() && gemm_npad(C) != C) HIP_CHECK(hipMemsetAsync(vT, 0, (size_t)B * gemm_npad(C) * S * sizeof(half_t), ex.ctx.stream));
+            if (!ex.dry() && (gemm_npad(C) != C || Sp != S)) HIP_CHECK(hipMemsetAsync(vT, 0, (size_t)B * gemm_npad(C) * Sp * sizeof(half_t), ex.ctx.stream));
             linear(ex, mid_att.q, n, C, M, q, C);
             for (int bi = 0; bi < B; ++bi) {   // K rows are laid out per image with Spad rows so they can serve as a GEMM "W"
                 linear(ex, mid_att.k, n + (size_t)bi * S * C, C, S, k + (size_t)bi * Spad * C, C);
                 GemmArgs g;   // V^T[c][s]
                 g.A0 = n + (size_t)bi * S * C; g.lda0 = C; g.C0 = C; g.M = S; g.N = C; g.K = C; g.taps = 1;
-                g.W = mid_att.v.W; g.Npad = mid_att.v.Npad; g.bias = mid_att.v.bias; g.D = vT + (size_t)bi * gemm_npad(C) * S; g.ldd = S;
+                g.W = mid_att.v.W; g.Npad = mid_att.v.Npad; g.bias = mid_att.v.bias; g.D = vT + (size_t)bi * gemm_npad(C) * Sp; g.ldd = Sp;
                 g.epi = EPI_TRANS;
                 run_gemm(ex, g);
             }
             {
                 GemmArgs g;   // scores[b] = q[b] k[b]^T / sqrt(C)
                 g.A0 = q; g.lda0 = C; g.C0 = C; g.M = S; g.N = S; g.K = C; g.taps = 1;
-                g.W = k; g.Npad = Spad; g.D = sc; g.ldd = S; g.alpha = 1.0f / sqrtf((float)C);
-                g.batch = B; g.sA = (long long)S * C; g.sW = (long long)Spad * C; g.sD = (long long)S * S;
+                g.W = k; g.Npad = Spad; g.D = sc; g.ldd = Sp; g.alpha = 1.0f / sqrtf((float)C);
+                g.batch = B; g.sA = (long long)S * C; g.sW = (long long)Spad * C; g.sD = (long long)S * Sp;
                 run_gemm(ex, g);
             }
-            if (!ex.dry()) launch_softmax_rows(ex.ctx, sc, (int64_t)B * S, S);
+            if (!ex.dry()) launch_softmax_rows(ex.ctx, sc, (int64_t)B * S, S, Sp);
             {
                 GemmArgs g;   // ao[b] = P[b] V[b]
-                g.A0 = sc; g.lda0 = S; g.C0 = S; g.M = S; g.N = C; g.K = S; g.taps = 1;
+                g.A0 = sc; g.lda0 = Sp; g.C0 = Sp; g.M = S; g.N = C; g.K = Sp; g.taps = 1;
                 g.W = vT; g.Npad = gemm_npad(C); g.D = ao; g.ldd = C;
-                g.batch = B; g.sA = (long long)S * S; g.sW = (long long)gemm_npad(C) * S; g.sD = (long long)S * C;
+                g.batch = B; g.sA = (long long)S * Sp; g.sW = (long long)gemm_npad(C) * Sp; g.sD = (long long)S * C;
                 run_gemm(ex, g);
             }
         }

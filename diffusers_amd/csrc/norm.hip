@@ -385,40 +385,41 @@ void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows
 }
 
 // ------------------------------------------------------------------------------------------ row softmax (VAE attention)
-__global__ void softmax_rows_kernel(half_t* X, long long rows, int cols)
+__global__ void softmax_rows_kernel(half_t* X, long long rows, int cols, int pitch)
 {
+    // rows of `pitch` elements (a multiple of 8); the first `cols` are scores, the rest is padding that is written as zeros
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= rows) return;
-    half_t* x = X + row * cols;
-    const int CX = cols >> 3;
+    half_t* x = X + row * pitch;
+    const int CX = pitch >> 3;
     float mx = -INFINITY;
     for (int cx = lane; cx < CX; cx += 64) {
         half8 v = *(const half8*)(x + cx * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) mx = fmaxf(mx, (float)v[j]);
+        for (int j = 0; j < 8; ++j) if (cx * 8 + j < cols) mx = fmaxf(mx, (float)v[j]);
     }
     mx = wave_max(mx);
     float sum = 0.f;
     for (int cx = lane; cx < CX; cx += 64) {
         half8 v = *(const half8*)(x + cx * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += __expf((float)v[j] - mx);
+        for (int j = 0; j < 8; ++j) if (cx * 8 + j < cols) sum += __expf((float)v[j] - mx);
     }
     const float inv = 1.0f / wave_sum(sum);
     for (int cx = lane; cx < CX; cx += 64) {
         half8 v = *(const half8*)(x + cx * 8);
         half8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(__expf((float)v[j] - mx) * inv);
+        for (int j = 0; j < 8; ++j) o[j] = cx * 8 + j < cols ? (half_t)(__expf((float)v[j] - mx) * inv) : (half_t)0.f;
         *(half8*)(x + cx * 8) = o;
     }
 }
 
-void launch_softmax_rows(const LaunchCtx& ctx, half_t* X, int64_t rows, int cols)
+void launch_softmax_rows(const LaunchCtx& ctx, half_t* X, int64_t rows, int cols, int pitch)
 {
-    SDE_REQUIRE(cols % 8 == 0, SDE_ERR_INVALID_ARGUMENT, "softmax_rows: cols must be a multiple of 8");
+    SDE_REQUIRE(pitch % 8 == 0 && cols > 0 && cols <= pitch, SDE_ERR_INVALID_ARGUMENT, "softmax_rows: pitch must be a multiple of 8 and >= cols");
     ProfScope ps(ctx, "softmax_rows", 0, 4.0 * rows * cols);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, ctx.stream, X, (long long)rows, cols);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv64(rows, 4)), dim3(256), 0, ctx.stream, X, (long long)rows, cols, pitch);
     HIP_CHECK(hipGetLastError());
 }

@@ -77,6 +77,19 @@ def test_sd15_unet_forward_image_size_not_a_multiple_of_64(sd15):
     assert rel_l2(got, ref) < 1e-2, rel_l2(got, ref)
 
 
+@pytest.mark.parametrize("h,w", [(9, 7), (13, 8)])
+def test_sd15_vae_decode_odd_latent(sd15, h, w):
+    """72 x 56 / 104 x 64 pixel images: 63 / 104 tokens in the VAE's 512-wide single-head attention (score rows pitched to 64 / 128)."""
+    from oracle import unet_ref
+    pipe, _, _, vw, vcfg = sd15
+    lat = np.random.default_rng(h * w).standard_normal((2, 4, h, w)).astype(np.float32)
+    with torch.no_grad():
+        ref = unet_ref.decode_latents(vw, vcfg, torch.from_numpy(lat)).numpy()
+    got = pipe.decode_latents(lat)
+    assert got.shape == ref.shape == (2, 8 * h, 8 * w, 3)
+    assert psnr(got, ref) >= 35.0, psnr(got, ref)
+
+
 def test_sd15_txt2img_three_steps_and_decode(sd15):
     from diffusers_amd import schedulers as N
     from diffusers_amd.pipeline import StableDiffusionTxt2ImgOptions

@@ -146,6 +146,26 @@ def test_txt2img_trace_vs_oracle(pipe, oracle_models, kind, steps, guidance, res
     assert psnr(res.images, ref_img) >= 35.0
 
 
+def test_txt2img_odd_latent_size(pipe, oracle_models):
+    """120 x 136 pixels (divisible by 8, not by 16): 15 x 17 latents through the whole loop and the decoder."""
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionTxt2ImgOptions
+    from oracle import schedulers as S, txt2img as T, unet_ref
+    uw, ucfg, vw, vcfg = oracle_models
+    B, h, w, steps = 2, 15, 17, 4
+    rng = np.random.default_rng(1517)
+    ehs = (rng.standard_normal((2 * B, 77, 64)) * 0.5).astype(np.float32)
+    init = rng.standard_normal((B, 4, h, w)).astype(np.float32)
+    unet = lambda x, t, e: unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), t, torch.from_numpy(e)).numpy()
+    ref = T.run(unet, S.make("dpmpp"), ehs, init, steps, 7.5)
+    res = StableDiffusionTxt2ImgOptions(height=h * 8, width=w * 8, steps=steps, text_embeddings=ehs, batch_size=B,
+                                        init_latents=init).run(pipe, N.DPMSolverMultistepScheduler.stable_diffusion_v1_optimized_default(), trace=True)
+    for i in range(res.unet_calls):
+        assert rel_l2(res.noise_pred[i], ref["noise_pred"][i]) < 1e-2, i
+    ref_img = unet_ref.decode_latents(vw, vcfg, torch.from_numpy(ref["final"])).numpy()
+    assert res.images.shape == ref_img.shape and psnr(res.images, ref_img) >= 35.0
+
+
 def test_txt2img_size_check_and_callbacks(pipe):
     from diffusers_amd import _lib, schedulers as N
     from diffusers_amd.pipeline import StableDiffusionTxt2ImgOptions
