@@ -207,6 +207,21 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         constexpr bool MASK = decltype(mask_tag)::value;
         const half_t* sK = sK_ + buf * 64 * KROW;
         const half_t* sV = sV_ + buf * 64 * VROW;
+        const int tq = fr >> 2, tp = fr & 3;
+        // DMA path: the transposed V reads go out FIRST, ahead of the K-fragment reads.  LDS returns in order, so the waits the
+        // compiler places for its own K reads (it does not know about the asm reads in front of them) also cover V, and the V
+        // latency hides behind the score MFMAs instead of sitting between the running-max phase and the exponentials.
+        fp16x4 vlo[2][DVT], vhi[2][DVT];
+        if constexpr (DMA) {
+            const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sV + (fg * 4 + tq) * VROW + tp * 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int dt = 0; dt < DVT; ++dt) {
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + dt * 16) * 2));
+                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + 16 * VROW + dt * 16) * 2));
+                }
+        }
         // scores S^T[key][q]: s[kt][qt][r] <-> key = kv0 + 16*kt + 4*fg + r, q = q0 + 16*qt + fr
         floatx4 s[4][2];
 #pragma unroll
@@ -286,7 +301,6 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         // be scheduled between the first tile's PV MFMAs.
         // A operand via transposed LDS reads: lane 4q'+p' of a 16-lane group addresses row (key) q', columns 4p'..4p'+3
         // and receives column (lane&15).  k-slot (fg, j): j<4 -> key tile 2*s2, reg j ; j>=4 -> key tile 2*s2+1, reg j-4.
-        const int tq = fr >> 2, tp = fr & 3;
         auto read_v = [&](int s2, int dt) {
             const half_t* a0 = sV + (s2 * 32 + fg * 4 + tq) * VROW + dt * 16 + tp * 4;
             fp16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)a0);
@@ -303,16 +317,7 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             // The transposed reads are issued from inline asm: the compiler orders every ds_read it can see behind ALL outstanding
             // LDS-DMA (s_waitcnt vmcnt(0)), which would drain the ring's prefetch.  Nothing else touches LDS between here and the
             // explicit lgkmcnt(0) below, so the compiler's own LDS bookkeeping is not disturbed.
-            fp16x4 vlo[2][DVT], vhi[2][DVT];
-            const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sV + (fg * 4 + tq) * VROW + tp * 4);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int dt = 0; dt < DVT; ++dt) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + dt * 16) * 2));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + 16 * VROW + dt * 16) * 2));
-                }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // long since satisfied: the K-fragment waits were behind these reads
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
