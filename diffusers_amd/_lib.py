@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsdengine.so")
+LIB_PATH = os.environ.get("SDE_LIB_PATH") or os.path.join(_HERE, "libsdengine.so")   # SDE_LIB_PATH: tuning hook (A/B builds)
 
 c_float_p = C.POINTER(C.c_float)
 
