@@ -11,6 +11,7 @@ collective), value = all images / max-over-ranks time.
 import argparse
 import ctypes as C
 import json
+import re
 import os
 import sys
 import time
@@ -72,6 +73,18 @@ def cpu_baseline(model_dir, seconds_budget=30.0):
             "sample": f"{n} timed UNet forwards (batch 2, fp32, 64x64 latent, S=77) + 1 VAE decode of one 512x512 image, "
                       f"extrapolated to Euler 20 steps (configs[0]); torch CPU oracle, ORT unavailable",
             "unet_s_per_call": t_unet, "vae_s_per_image": t_vae, "unet_it_per_s": 1.0 / t_unet}
+
+
+# engine profiler class -> HIP kernel symbol(s) in a rocprofv3 kernel trace
+ROCPROF_SYMBOL = {
+    "conv3x3_mfma_256x320": "gemm_big_kernel<true, UPS, 5, 0>", "conv3x3_mfma_256x256": "gemm_big_kernel<true, UPS, 4, 0>",
+    "gemm_mfma_256x320": "gemm_big_kernel<false, false, 5, 0> (shared with gemm_geglu_mfma_256x320)",
+    "gemm_geglu_mfma_256x320": "gemm_big_kernel<false, false, 5, 0> (shared with gemm_mfma_256x320)",
+    "gemm_mfma_256x256": "gemm_big_kernel<false, false, 4, 0>",
+    "conv3x3_mfma_256x160": "gemm_midl_kernel<true, UPS>", "gemm_mfma_256x160": "gemm_mid_kernel<false, false, 0>",
+    "conv3x3_mfma": "gemm_mfma_kernel<BM, BN, true>", "gemm_mfma": "gemm_mfma_kernel<BM, BN, false>",
+    "splitk_reduce": "splitk_reduce_kernel",
+}
 
 
 def main():
@@ -190,7 +203,9 @@ def main():
             traffic = None
         if dom["flops"] > 0:
             ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            roof = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+            # the HIP kernel symbol(s) behind the class, as `rocprofv3 --kernel-trace --stats` prints them (profiles/*kernel_stats*.csv)
+            sym = ROCPROF_SYMBOL.get(dom["name"]) or re.sub(r"^attn_mfma<(\d+),(\d+)>$", r"attn_mfma_kernel<\1, \2, ONES, FOLD>", dom["name"])
+            roof = {"kernel": dom["name"], "rocprof_symbol": sym, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": traffic, "launches": dom["launches"],
                     "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2),
                     "flop_per_launch": dom["flops"] / dom["launches"], "profiled_step_ms": round(rp.total_ms, 2)}

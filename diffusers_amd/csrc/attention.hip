@@ -576,8 +576,16 @@ void launch_attention(const LaunchCtx& ctx, const AttnArgs& a)
     const double flops = 4.0 * a.NB * a.heads * (double)a.Sq * a.Skv * a.d;
     const double bytes = 2.0 * a.NB * a.heads * ((double)a.Sq * a.d * 2 + (double)a.Skv * a.d * 2);
     if (!ctx.force_naive && attention_mfma_supported(a)) {
-        ProfScope ps(ctx, a.Sq == a.Skv ? "attn_self_mfma" : "attn_cross_mfma", flops, bytes);
         const int d = a.d;
+        // one profiler class per kernel instance (self- and cross-attention of one head dim share it), named so that it can be
+        // matched against the kernel symbol rocprofv3 reports: attn_mfma<DQK,DVT> <-> attn_mfma_kernel<DQK, DVT, ONES, FOLD>
+        static thread_local char cls[32];
+        {
+            const int dvt = d <= 16 ? 1 : (d <= 32 ? 2 : (d <= 96 ? (d + 15) / 16 : (d <= 128 ? 8 : 10)));
+            const int dqk = d <= 32 ? 32 : (d <= 64 ? 64 : (d <= 96 ? 96 : (d <= 128 ? 128 : 160)));
+            snprintf(cls, sizeof(cls), "attn_mfma<%d,%d>", dqk, dvt);
+        }
+        ProfScope ps(ctx, cls, flops, bytes);
         if (d <= 16) launch_attn_t<32, 1>(ctx, p);
         else if (d <= 32) launch_attn_t<32, 2>(ctx, p);
         else if (d <= 48) launch_attn_t<64, 3>(ctx, p);

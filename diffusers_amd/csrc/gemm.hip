@@ -326,11 +326,15 @@ static void launch_mfma(const LaunchCtx& ctx, GemmDev& p, int batch)
         if (sk > 1) { p.splitk = sk; p.ws = ctx.splitk_ws; }
     }
     dim3 grid(p.nbm * p.nbn, p.splitk, batch);
-    hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx.stream, p);
-    if (p.splitk > 1) {
-        long long total = (long long)p.M * (p.Npad >> 2);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);
-    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx.stream, p);   // p.splitk > 1: the caller follows up with launch_splitk_reduce
+}
+
+// split-K second pass (own profiler class: one class per kernel symbol)
+static void launch_splitk_reduce(const LaunchCtx& ctx, const GemmDev& p)
+{
+    const long long total = (long long)p.M * (p.Npad >> 2);
+    ProfScope ps(ctx, "splitk_reduce", 0.0, ((double)p.splitk * 4.0 + 2.0) * (double)p.M * p.Npad);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);
 }
 
 // profiler class name; SDE_PROF_SHAPES=1 appends the problem shape (tools/shape_profile.py)
@@ -366,13 +370,12 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;   // slab traffic must stay small next to the GEMM
         }
         if (big_env == 2 || ctx.force_big || tiles * sk >= 192 || a.epi == EPI_GEGLU_PAIR) {
-            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma_256x320" : (a.epi == EPI_GEGLU_PAIR ? "gemm_geglu_mfma_256x320" : "gemm_mfma_256x320"), a, "B"), flops, bytes);
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
-            launch_gemm_big(ctx, p, a.batch, a.taps == 9);
-            if (sk > 1) {
-                long long total = (long long)p.M * (p.Npad >> 2);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);
+            {
+                ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma_256x320" : (a.epi == EPI_GEGLU_PAIR ? "gemm_geglu_mfma_256x320" : "gemm_mfma_256x320"), a, "B"), flops, bytes);
+                launch_gemm_big(ctx, p, a.batch, a.taps == 9);
             }
+            if (sk > 1) launch_splitk_reduce(ctx, p);
             HIP_CHECK(hipGetLastError());
             return;
         }
@@ -391,8 +394,9 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;
         }
         if (mid_env == 2 || ctx.force_mid || tiles * sk >= 192) {
-            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma_256x160" : "gemm_mfma_256x160", a, "M"), flops, bytes);
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
+            {
+            ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma_256x160" : "gemm_mfma_256x160", a, "M"), flops, bytes);
 #ifdef SDE_DIAG
             static const bool stamps = getenv("SDE_STAMPS") && atoi(getenv("SDE_STAMPS"));
             if (stamps && sk == 1) p.stamps = (unsigned*)ctx.splitk_ws;
@@ -412,15 +416,14 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
                 }
             }
 #endif
-            if (sk > 1) {
-                long long total = (long long)p.M * (p.Npad >> 2);
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, ctx.stream, p);
             }
+            if (sk > 1) launch_splitk_reduce(ctx, p);
             HIP_CHECK(hipGetLastError());
             return;
         }
     }
     if (!ctx.force_naive && gemm_mfma_supported(a)) {
+        {
         ProfScope ps(ctx, prof_name(a.taps == 9 ? "conv3x3_mfma" : (a.epi == EPI_GEGLU ? "gemm_geglu_mfma" : "gemm_mfma"), a, "S"), flops, bytes);
         // tile height: 128 rows unless that leaves the chip (256 CUs x 2 blocks) under-filled and split-K (<= 4 ways,
         // long K only) cannot make up for it -> 64 rows.  Measured on MI355X at UNet batch 16 (tools/microbench.py).
@@ -438,6 +441,8 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             if (bn160) { if (small_m) launch_mfma<64, 160, false>(ctx, p, a.batch); else launch_mfma<128, 160, false>(ctx, p, a.batch); }
             else       { if (small_m) launch_mfma<64, 128, false>(ctx, p, a.batch); else launch_mfma<128, 128, false>(ctx, p, a.batch); }
         }
+        }
+        if (p.splitk > 1) launch_splitk_reduce(ctx, p);
     } else {
         ProfScope ps(ctx, a.taps == 9 ? "conv3x3_plain" : "gemm_plain", flops, bytes);
         const int Nout = (a.epi == EPI_GEGLU || a.epi == EPI_GEGLU_PAIR) ? a.N / 2 : a.N;

@@ -32,25 +32,21 @@ def kernel_class(name: str) -> str:
         nt = t[2] if len(t) > 2 else "5"
         tile = "256x320" if nt == "5" else "256x256"
         return ("conv3x3_mfma_" if conv else "gemm_mfma_") + tile
+    if base == "gemm_midl_kernel":      # loader-wave variant: the 3x3 convolutions of the 256x160 class
+        return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + "256x160"
     if base == "gemm_mid_kernel":
         return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + "256x160"
     if base == "gemm_mfma_kernel":
         conv = len(t) > 2 and t[2] == "true"
         return ("conv3x3_mfma_" if conv else "gemm_mfma_") + f"{t[0]}x{t[1]}" if len(t) > 1 else "gemm_mfma"
     if base == "attn_mfma_kernel":
-        return f"attn_mfma<dqk={t[0]},dvt={t[1]}>" if len(t) > 1 else "attn_mfma"
+        return f"attn_mfma<{t[0]},{t[1]}>" if len(t) > 1 else "attn_mfma"
     return base
 
 
 def engine_class(name: str, dur_ns: float, split: dict) -> str:
-    """Engine-profiler class name (what bench.py's kernel table uses).  Self- and cross-attention share kernel instances; they
-    are told apart by duration (self-attention over 4096/1024/256 keys runs several times longer than 77 keys)."""
+    """Engine-profiler class name (what bench.py's kernel table uses)."""
     k = kernel_class(name)
-    if k.startswith("attn_mfma"):
-        lo, hi = split.get(k, (dur_ns, dur_ns))
-        if hi > 3 * lo:
-            return "attn_self_mfma" if dur_ns > (lo * hi) ** 0.5 else "attn_cross_mfma"
-        return "attn_self_mfma"
     if k.startswith("conv3x3_mfma_") or k.startswith("gemm_mfma_"):
         base, tile = k.rsplit("_", 1)
         return base if tile in ("128x160", "64x160", "128x128", "64x128") else k
