@@ -297,6 +297,8 @@ static bool ends_with(const std::string& s, const char* suf)
 //   MatMul_KV_n / MatMul_QKV_n   weight [Cin, heads*2*d] / [C, heads*3*d], per-head interleave   (fusion_attention_unet.py:164-280)
 //   com.microsoft.GroupNorm      gamma / beta as <node>_gamma / <node>_beta                       (fusion_group_norm.py:108-160)
 //   com.microsoft.FastGelu       tanh-form GELU in place of the exact one                         (fusion_gelu_approximation.py)
+//   `*-nv` presets (optimize.py:102-130): NhwcConv keeps the OIHW initializer behind a Transpose (fusion_nhwc_conv.py:62-64, update_weight=False),
+//   BiasSplitGelu / BiasAdd / SkipLayerNormalization keep the named bias / gamma / beta initializers: all bound by name, nothing to unpack
 // The module a fused node belongs to is read off the first NAMED node that consumes its result (to_out.0 / proj_attn / conv1 ...).
 namespace {
 struct FusedBinder {
@@ -309,10 +311,21 @@ struct FusedBinder {
         for (int i = 0; i < (int)m.nodes.size(); ++i)
             for (auto& in : m.nodes[(size_t)i].inputs) consumers[in].push_back(i);
     }
+    // module path of a node that still carries the exporter's name; NhwcConv nodes are renamed "NhwcConv_<k>-<old name>"
+    // (fusion_nhwc_conv.py:69-75), the path follows the dash
+    static std::string path_of(const OnnxNode& n)
+    {
+        if (n.op_type == "NhwcConv") {
+            const size_t dash = n.name.find("-/");
+            return dash == std::string::npos ? "" : n.name.substr(dash + 1);
+        }
+        return n.name;
+    }
     static bool named(const OnnxNode& n)
     {
-        if (n.name.size() < 2 || n.name[0] != '/') return false;
-        return n.op_type == "MatMul" || n.op_type == "Conv" || n.op_type == "Gemm";
+        const std::string p = path_of(n);
+        if (p.size() < 2 || p[0] != '/') return false;
+        return n.op_type == "MatMul" || n.op_type == "Conv" || n.op_type == "Gemm" || n.op_type == "NhwcConv";
     }
     // module ("a.b.c") of the first named MatMul / Conv / Gemm reachable from `tensor` through unnamed nodes (breadth first)
     std::string consumer_module(const std::string& tensor) const
@@ -325,7 +338,7 @@ struct FusedBinder {
                 if (it == consumers.end()) continue;
                 for (int ni : it->second) {
                     const OnnxNode& n = m.nodes[(size_t)ni];
-                    if (named(n)) return module_of(n.name);
+                    if (named(n)) return module_of(path_of(n));
                     for (auto& o : n.outputs) next.push_back(o);
                 }
             }

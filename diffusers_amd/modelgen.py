@@ -266,7 +266,7 @@ class GraphWriter:
     """Accumulates nodes/initializers; weights above ``external_threshold`` bytes total go to one
     external file, as sd2pyke.py:306-316 does for > 2000 MB UNets."""
 
-    def __init__(self, dtype=np.float32, fused: bool = False, approximate_gelu: bool = False):
+    def __init__(self, dtype=np.float32, fused: bool = False, approximate_gelu: bool = False, nv: bool = False):
         """``fused``: emit the graph the reference's optimizer leaves behind (scripts/optimize.py --preset gpu:
         com.microsoft Attention / MultiHeadAttention with packed KV / GroupNorm, LayerNormalization, Gelu or FastGelu) instead
         of the raw torch export.  Weight packing follows scripts/_optimizer/fusion_attention_unet.py:215-226,231-280,
@@ -279,6 +279,10 @@ class GraphWriter:
         self.cidx = 0
         self.fused = fused
         self.approximate_gelu = approximate_gelu
+        # ``nv``: additionally the fusions of the `*-nv` presets (scripts/optimize.py:102-130): NhwcConv behind weight / activation
+        # Transposes (fusion_nhwc_conv.py:35-90, update_weight=False), BiasSplitGelu (fusion_biassplitgelu.py:88-112), BiasAdd
+        # (fusion_bias_add.py:30-60) and SkipLayerNormalization for the residual add in front of norm2 / norm3
+        self.nv = nv and fused
         self.fcount: Dict[str, int] = {}
 
     def fname(self, prefix: str) -> str:
@@ -317,6 +321,15 @@ class GraphWriter:
         pad = 1 if k == 3 else 0
         attrs = (_attr_ints("dilations", [1, 1]) + _attr_i("group", 1) + _attr_ints("kernel_shape", [k, k]) +
                  _attr_ints("pads", [pad] * 4) + _attr_ints("strides", [stride, stride]))
+        if self.nv:
+            xin = x + "_NHWC_in"
+            self.node("Transpose", self.fname("Transpose_NCHW_to_NHWC"), [x], [xin], _attr_ints("perm", [0, 2, 3, 1]))
+            wt = pname + ".weight_NHWC"
+            self.node("Transpose", self.fname("Transpose_NCHW_to_NHWC"), [pname + ".weight"], [wt], _attr_ints("perm", [0, 2, 3, 1]))
+            name = self.fname("NhwcConv")
+            self.node("NhwcConv", f"{name}-{scope}/Conv", [xin, wt, pname + ".bias"], [f"{name}_out-{out}"], attrs, "com.microsoft")
+            self.node("Transpose", self.fname("Transpose_NHWC_to_NCHW"), [f"{name}_out-{out}"], [out], _attr_ints("perm", [0, 3, 1, 2]))
+            return out
         self.node("Conv", f"{scope}/Conv", [x, pname + ".weight", pname + ".bias"], [out], attrs)
         return out
 
@@ -402,6 +415,16 @@ class GraphWriter:
         a = self.tmp(scope, "Add_1")
         self.node("Add", f"{scope}/Add_1", [m, pname + ".bias"], [a])
         return a
+
+    def skip_layer_norm(self, scope, pname, w, x, skip, eps=1e-5):
+        """com.microsoft.SkipLayerNormalization(input, skip, gamma, beta) -> (normalized, _, _, input + skip): what the optimizer's
+        skip_layer_norm option leaves for `Add` + LayerNormalization (onnx_model_unet.py:120-121)."""
+        self.init(pname + ".weight", w[pname + ".weight"])
+        self.init(pname + ".bias", w[pname + ".bias"])
+        out, summed = self.tmp(scope, "Add_1"), self.tmp(scope, "SkipSum")
+        self.node("SkipLayerNormalization", self.fname("SkipLayerNorm"), [x, skip, pname + ".weight", pname + ".bias"], [out, "", "", summed],
+                  _attr_f("epsilon", eps), "com.microsoft")
+        return out, summed
 
     def unary(self, op, scope, x, name=None):
         out = self.tmp(scope, op)
@@ -532,33 +555,46 @@ def _emit_transformer(gw: GraphWriter, scope, p, w, x, ctx, heads, c, lin, group
     h = gw.linear(scope + "/proj_in", p + ".proj_in", w, h) if lin else gw.conv(scope + "/proj_in", p + ".proj_in", w, h, k=1)
     bs, bp = scope + "/transformer_blocks.0", p + ".transformer_blocks.0"
     n = gw.layer_norm(bs + "/norm1", bp + ".norm1", w, h)
-    h = gw.binary("Add", bs, h, _emit_attention(gw, bs + "/attn1", bp + ".attn1", w, n, n, heads, c))
-    n = gw.layer_norm(bs + "/norm2", bp + ".norm2", w, h)
-    h = gw.binary("Add", bs, h, _emit_attention(gw, bs + "/attn2", bp + ".attn2", w, n, ctx, heads, c), "Add_1")
-    n = gw.layer_norm(bs + "/norm3", bp + ".norm3", w, h)
-    y = gw.linear(bs + "/ff/net.0/proj", bp + ".ff.net.0.proj", w, n)
-    if gw.fused:
-        # fusion_gelu.py -> Gelu ; with --approximate-gelu fusion_gelu_approximation.py turns it into com.microsoft.FastGelu (tanh form)
+    if gw.nv:
+        n, h = gw.skip_layer_norm(bs + "/norm2", bp + ".norm2", w, _emit_attention(gw, bs + "/attn1", bp + ".attn1", w, n, n, heads, c), h)
+        n, h = gw.skip_layer_norm(bs + "/norm3", bp + ".norm3", w, _emit_attention(gw, bs + "/attn2", bp + ".attn2", w, n, ctx, heads, c), h)
+        y = gw.linear(bs + "/ff/net.0/proj", bp + ".ff.net.0.proj", w, n, bias=False)
+        gw.init(bp + ".ff.net.0.proj.bias", w[bp + ".ff.net.0.proj.bias"])
         g = gw.tmp(bs + "/ff/net.0", "Mul_3")
-        if gw.approximate_gelu:
-            gw.node("FastGelu", gw.fname("FastGelu_Gelu_Approximation"), [y], [g], b"", "com.microsoft")
-        else:
-            gw.node("Gelu", gw.fname("Gelu"), [y], [g], b"", "com.microsoft")
-        y = gw.binary("Mul", bs + "/ff/net.0", y, g)
+        gw.node("BiasSplitGelu", gw.fname("BiasSplitGelu"), [y, bp + ".ff.net.0.proj.bias"], [g], b"", "com.microsoft")
+        y = gw.linear(bs + "/ff/net.2", bp + ".ff.net.2", w, g, bias=False)
+        gw.init(bp + ".ff.net.2.bias", w[bp + ".ff.net.2.bias"])
+        out = gw.tmp(bs, "Add_2")
+        gw.node("BiasAdd", gw.fname("BiasAdd"), [y, bp + ".ff.net.2.bias", h], [out], b"", "com.microsoft")
+        h = out
     else:
-        # exact-erf GELU on the gate half (fusion_gelu.py:27-45 pattern), value half first
-        g = gw.binary("Div", bs + "/ff/net.0", y, gw.const(bs, np.asarray(1.4142135381698608, np.float32)))
-        g = gw.unary("Erf", bs + "/ff/net.0", g)
-        y = gw.binary("Mul", bs + "/ff/net.0", y, g)
-    y = gw.linear(bs + "/ff/net.2", bp + ".ff.net.2", w, y)
-    h = gw.binary("Add", bs, h, y, "Add_2")
+        h = gw.binary("Add", bs, h, _emit_attention(gw, bs + "/attn1", bp + ".attn1", w, n, n, heads, c))
+        n = gw.layer_norm(bs + "/norm2", bp + ".norm2", w, h)
+        h = gw.binary("Add", bs, h, _emit_attention(gw, bs + "/attn2", bp + ".attn2", w, n, ctx, heads, c), "Add_1")
+        n = gw.layer_norm(bs + "/norm3", bp + ".norm3", w, h)
+        y = gw.linear(bs + "/ff/net.0/proj", bp + ".ff.net.0.proj", w, n)
+        if gw.fused:
+            # fusion_gelu.py -> Gelu ; with --approximate-gelu fusion_gelu_approximation.py turns it into com.microsoft.FastGelu (tanh form)
+            g = gw.tmp(bs + "/ff/net.0", "Mul_3")
+            if gw.approximate_gelu:
+                gw.node("FastGelu", gw.fname("FastGelu_Gelu_Approximation"), [y], [g], b"", "com.microsoft")
+            else:
+                gw.node("Gelu", gw.fname("Gelu"), [y], [g], b"", "com.microsoft")
+            y = gw.binary("Mul", bs + "/ff/net.0", y, g)
+        else:
+            # exact-erf GELU on the gate half (fusion_gelu.py:27-45 pattern), value half first
+            g = gw.binary("Div", bs + "/ff/net.0", y, gw.const(bs, np.asarray(1.4142135381698608, np.float32)))
+            g = gw.unary("Erf", bs + "/ff/net.0", g)
+            y = gw.binary("Mul", bs + "/ff/net.0", y, g)
+        y = gw.linear(bs + "/ff/net.2", bp + ".ff.net.2", w, y)
+        h = gw.binary("Add", bs, h, y, "Add_2")
     h = gw.linear(scope + "/proj_out", p + ".proj_out", w, h) if lin else gw.conv(scope + "/proj_out", p + ".proj_out", w, h, k=1)
     return gw.binary("Add", scope, h, x)
 
 
 def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32, external: bool | None = None,
-                    fused: bool = False, approximate_gelu: bool = False):
-    gw = GraphWriter(dtype, fused, approximate_gelu)
+                    fused: bool = False, approximate_gelu: bool = False, nv: bool = False):
+    gw = GraphWriter(dtype, fused, approximate_gelu, nv)
     boc = list(cfg["block_out_channels"])
     lpb, lin, groups, eps = cfg["layers_per_block"], cfg["use_linear_projection"], cfg["norm_num_groups"], cfg["norm_eps"]
     t = gw.unary("Cast", "", "timestep")
@@ -613,8 +649,8 @@ def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.flo
     gw.serialize(path, ["sample", "timestep", "encoder_hidden_states"], ["out_sample"], "unet_weights.bin" if external else None)
 
 
-def write_vae_decoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32, fused: bool = False):
-    gw = GraphWriter(dtype, fused)
+def write_vae_decoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32, fused: bool = False, nv: bool = False):
+    gw = GraphWriter(dtype, fused, False, nv)
     groups = cfg["norm_num_groups"]
     boc = list(reversed(cfg["block_out_channels"]))
     z = gw.conv("/post_quant_conv", "post_quant_conv", w, "latent_sample", k=1)
@@ -697,15 +733,16 @@ vae-decoder = "{vae_hash}"
 
 
 def write_model_dir(root: str, unet_cfg: dict, vae_cfg: dict, seed: int = 42, dtype=np.float32,
-                    unet_gain: float = 1.0, external: bool | None = None, fused: bool = False, approximate_gelu: bool = False):
+                    unet_gain: float = 1.0, external: bool | None = None, fused: bool = False, approximate_gelu: bool = False,
+                    nv: bool = False):
     """Writes pyke-diffusers.toml + unet.onnx(+unet_weights.bin) + vae_decoder.onnx with random weights.
     The text-encoder/tokenizer entries are placeholders: CLIP stays with the caller."""
     os.makedirs(root, exist_ok=True)
     uw = random_weights(unet_param_shapes(unet_cfg), seed, unet_gain)
-    write_unet_onnx(os.path.join(root, "unet.onnx"), unet_cfg, uw, dtype, external, fused, approximate_gelu)
+    write_unet_onnx(os.path.join(root, "unet.onnx"), unet_cfg, uw, dtype, external, fused, approximate_gelu, nv)
     del uw
     vw = random_weights(vae_decoder_param_shapes(vae_cfg), seed + 1)
-    write_vae_decoder_onnx(os.path.join(root, "vae_decoder.onnx"), vae_cfg, vw, dtype, fused)
+    write_vae_decoder_onnx(os.path.join(root, "vae_decoder.onnx"), vae_cfg, vw, dtype, fused, nv)
     with open(os.path.join(root, "pyke-diffusers.toml"), "w") as f:
         f.write(TOML_TEMPLATE.format(unet_hash=f"{seed:032x}", vae_hash=f"{seed + 1:032x}"))
     return root

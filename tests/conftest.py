@@ -69,6 +69,17 @@ def tiny_model_dir_fused_f16(tmp_path_factory):
 
 
 @pytest.fixture(scope="session")
+def tiny_model_dir_fused_nv(tmp_path_factory):
+    """The `*-nv` presets (scripts/optimize.py:102-130): on top of the fused dialect, NhwcConv behind activation / weight Transposes,
+    BiasSplitGelu, BiasAdd and SkipLayerNormalization."""
+    from diffusers_amd import modelgen
+    d = tmp_path_factory.mktemp("tiny_sd_fused_nv")
+    ucfg, vcfg = _tiny_cfgs()
+    modelgen.write_model_dir(str(d), ucfg, vcfg, seed=7, fused=True, nv=True)
+    return str(d)
+
+
+@pytest.fixture(scope="session")
 def tiny_model_dir_fused_fastgelu(tmp_path_factory):
     """As above with --approximate-gelu: the feed-forward GELU is com.microsoft.FastGelu (tanh form)."""
     from diffusers_amd import modelgen

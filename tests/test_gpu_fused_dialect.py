@@ -36,6 +36,24 @@ def test_fused_unet_matches_raw_export(tiny_model_dir, tiny_model_dir_fused):
         raw.close(); fused.close()
 
 
+def test_nv_preset_dialect_matches_raw_export(tiny_model_dir, tiny_model_dir_fused_nv):
+    """NhwcConv (weights still OIHW initializers behind a Transpose, fusion_nhwc_conv.py:62-64 with update_weight=False),
+    BiasSplitGelu, BiasAdd, SkipLayerNormalization: same named initializers, so the loader must reach the same device weights."""
+    from diffusers_amd.pipeline import StableDiffusionPipeline
+    from oracle import onnx_io
+    ops = {n.op_type for n in onnx_io.load(tiny_model_dir_fused_nv + "/unet.onnx").nodes}
+    assert {"NhwcConv", "BiasSplitGelu", "BiasAdd", "SkipLayerNormalization", "Attention", "MultiHeadAttention", "GroupNorm"} <= ops
+    assert "Conv" not in ops
+    raw, nv = StableDiffusionPipeline(tiny_model_dir), StableDiffusionPipeline(tiny_model_dir_fused_nv)
+    try:
+        x, ehs = _inputs()
+        assert np.array_equal(raw.unet(x, 500.0, ehs), nv.unet(x, 500.0, ehs))
+        lat = np.random.default_rng(3).standard_normal((1, 4, 16, 16)).astype(np.float32)
+        assert np.isfinite(nv.vae_decoder(lat)).all()
+    finally:
+        raw.close(); nv.close()
+
+
 def test_fused_f16_unet_close_to_raw_export(tiny_model_dir, tiny_model_dir_fused_f16):
     from diffusers_amd.pipeline import StableDiffusionPipeline
     raw, fused = StableDiffusionPipeline(tiny_model_dir), StableDiffusionPipeline(tiny_model_dir_fused_f16)
