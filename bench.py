@@ -159,11 +159,11 @@ def main():
         one_step()
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    unet_ms = vae_ms = 0.0
+    unet_ms = vae_ms = enq_ms = 0.0
     calls = 0
     for _ in range(args.steps):
         r = one_step()
-        unet_ms += r.unet_ms; vae_ms += r.vae_ms; calls += r.unet_calls
+        unet_ms += r.unet_ms; vae_ms += r.vae_ms; calls += r.unet_calls; enq_ms += r.host_enqueue_ms
     torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -230,6 +230,7 @@ def main():
                    "unet_calls_per_step": calls // max(1, args.steps), "reference_quirks": True},
         "unet_it_per_s": round(calls / (unet_ms * 1e-3), 3) if unet_ms else None,
         "unet_ms_per_call": round(unet_ms / max(1, calls), 3), "vae_ms_per_batch": round(vae_ms / args.steps, 2),
+        "host_enqueue_ms_per_unet_call": round(enq_ms / max(1, calls), 3),   # host time to enqueue one UNet call's launches (no waiting)
         "effective_tflops_per_gpu": round(value / world * per_image_tflop, 1),
         "mfma_roofline_frac_end_to_end": round(value / world * per_image_tflop / PEAK_TFLOPS_F16, 4),
         "model_load_s": round(load_s, 1),

@@ -51,7 +51,8 @@ class Txt2ImgOpts(C.Structure):
 
 
 class RunStats(C.Structure):
-    _fields_ = [("unet_calls", C.c_int), ("total_ms", C.c_float), ("unet_ms", C.c_float), ("vae_ms", C.c_float)]
+    _fields_ = [("unet_calls", C.c_int), ("total_ms", C.c_float), ("unet_ms", C.c_float), ("vae_ms", C.c_float),
+                ("host_enqueue_ms", C.c_float)]
 
 
 class KernelStat(C.Structure):

@@ -615,11 +615,14 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             launch_pack_latents(e->ctx, d_lat, e->x_packed.as<half_t>(), B, (cfg && !half) ? 2 : 1, C, h, w, Cp, 1.0f / div);
         }
         int unet_calls = 0;
+        double enqueue_ms = 0.0;
         std::vector<float> cb_buf;
         for (int i = 0; i < nt; ++i) {
             const float t = ts[(size_t)i];
+            const auto tq0 = std::chrono::steady_clock::now();
             unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, e->ehs_h.as<half_t>() + half_off * B * S * D, S, i == 0,
                      e->model_out.as<float>() + half_off * per);                                             // :283
+            enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
             ++unet_calls;
             if (half) {
                 HIP_CHECK(hipStreamSynchronize(st));
@@ -722,6 +725,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             float a = 0, b = 0;
             (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2);
             stats->unet_calls = unet_calls; stats->unet_ms = a; stats->vae_ms = b; stats->total_ms = a + b;
+            stats->host_enqueue_ms = (float)enqueue_ms;
         }
         (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
     });

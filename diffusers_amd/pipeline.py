@@ -128,6 +128,7 @@ class Txt2ImgResult:
     total_ms: float = 0.0
     unet_ms: float = 0.0
     vae_ms: float = 0.0
+    host_enqueue_ms: float = 0.0
     noise_pred: Optional[np.ndarray] = None  # [n_steps,B,4,h,w] when trace=True
     latents: Optional[np.ndarray] = None     # [n_steps,B,4,h,w] when trace=True
     final_latents: Optional[np.ndarray] = None
@@ -305,6 +306,7 @@ class StableDiffusionTxt2ImgOptions:
                 raise pair_errors[0] from err
             raise
         res.unet_calls, res.total_ms, res.unet_ms, res.vae_ms = st.unet_calls, st.total_ms, st.unet_ms, st.vae_ms
+        res.host_enqueue_ms = st.host_enqueue_ms
         if trace and res.noise_pred is not None:
             res.noise_pred = res.noise_pred[:st.unet_calls]
             res.latents = res.latents[:st.unet_calls]

@@ -189,7 +189,8 @@ typedef struct sde_txt2img_opts {
 void sde_txt2img_opts_default(sde_txt2img_opts* o);
 
 typedef struct sde_run_stats {
-    int unet_calls; float total_ms, unet_ms, vae_ms;
+    int unet_calls; float total_ms, unet_ms, vae_ms;   /* HIP-event times on the engine's stream */
+    float host_enqueue_ms;   /* host wall time spent enqueueing the UNet calls (no waiting): << unet_ms means the loop is not launch-bound */
 } sde_run_stats;
 
 /* Runs the whole loop on the device; `scheduler` is left in the post-run state the reference
