@@ -19,6 +19,10 @@
 
 #include <algorithm>
 
+#include <mutex>
+#include <set>
+#include <utility>
+
 #include "gemm_common.h"
 
 // ------------------------------------------------------------------------------------------ MFMA kernel
@@ -304,16 +308,24 @@ bool gemm_mfma_supported(const GemmArgs& a)
     return true;
 }
 
+void allow_dynamic_lds(const void* kernel, int bytes)
+{
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, kernel})) return;
+    HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({dev, kernel});
+}
+
 template <int BM, int BN, bool CONV>
 static void launch_mfma(const LaunchCtx& ctx, GemmDev& p, int batch)
 {
-    static bool attr_set = false;
     constexpr int smem = 2 * (BM + BN) * 128;
     auto kern = gemm_mfma_kernel<BM, BN, CONV>;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
-        attr_set = true;
-    }
+    allow_dynamic_lds((const void*)kern, smem);
     p.nbm = cdiv(p.M, BM);
     p.nbn = p.Npad / BN;
     // split-K when the tile grid cannot fill the chip (2 blocks/CU x 256 CUs) and K is long: partial slabs + reduce kernel

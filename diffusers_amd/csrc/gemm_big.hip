@@ -404,12 +404,8 @@ bool gemm_big_supported(const GemmArgs& a)
 template <bool CONV, bool UPS, int NT, int VAR = 0>
 static void launch_big_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
-    static bool attr_set = false;
     auto kern = gemm_big_kernel<CONV, UPS, NT, VAR>;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes(NT)));
-        attr_set = true;
-    }
+    allow_dynamic_lds((const void*)kern, smem_bytes(NT));
     hipLaunchKernelGGL(kern, grid, dim3(512), smem_bytes(NT), ctx.stream, p);
 }
 

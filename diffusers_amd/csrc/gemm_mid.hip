@@ -534,24 +534,16 @@ bool gemm_mid_supported(const GemmArgs& a)
 template <bool CONV, bool UPS, int VAR = 0>
 static void launch_mid_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
-    static bool attr_set = false;
     auto kern = gemm_mid_kernel<CONV, UPS, VAR>;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        attr_set = true;
-    }
+    allow_dynamic_lds((const void*)kern, SMEM_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
 }
 
 template <bool CONV, bool UPS>
 static void launch_midl_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
-    static bool attr_set = false;
     auto kern = gemm_midl_kernel<CONV, UPS>;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        attr_set = true;
-    }
+    allow_dynamic_lds((const void*)kern, SMEM_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(768), SMEM_BYTES, ctx.stream, p);
 }
 

@@ -22,6 +22,10 @@ struct LaunchCtx {
     int splitk_force = 0;           // tuning hook: >0 forces this split factor where split-K applies
 };
 // RAII bracket: records HIP events around a launch when profiling is on.
+// Raises a kernel's dynamic-LDS limit once per (device, kernel): the attribute is per device, and engines on several GPUs (or on
+// several host threads) may share this process.
+void allow_dynamic_lds(const void* kernel, int bytes);
+
 struct ProfScope {
     ProfScope(const LaunchCtx& ctx, const char* name, double flops, double bytes);
     ~ProfScope();
