@@ -563,7 +563,8 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         const int Cp = UNetModel::kInPad;
         hipStream_t st = e->stream;
 
-        const uint64_t seed = o->has_seed ? o->seed : std::random_device{}();
+        std::random_device rd;   // thread_rng().gen::<u64>() (:248): 64 fresh bits when no seed is given
+        const uint64_t seed = o->has_seed ? o->seed : ((uint64_t)rd() << 32 | rd());
         // :249,267 -- StdRng::seed_from_u64(seed) / (seed + 31337), restated in rng.h (u64 add wraps in release builds)
         sde::ChaChaRng rng = sde::ChaChaRng::seed_from_u64(seed), sched_rng = sde::ChaChaRng::seed_from_u64(seed + 31337);
 
@@ -605,8 +606,12 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         if (want_taps) e->taps.ensure(per * 4);
         if (o->has_rescale_cfg && cfg) e->scratch_f.ensure(4096);
 
-        hipEvent_t ev0, ev1, ev2;
-        HIP_CHECK(hipEventCreate(&ev0)); HIP_CHECK(hipEventCreate(&ev1)); HIP_CHECK(hipEventCreate(&ev2));
+        struct Events {   // destroyed on every exit path (an error inside the loop throws past the end of this function)
+            hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+            ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+        } evs;
+        for (hipEvent_t& x : evs.e) HIP_CHECK(hipEventCreate(&x));
+        const hipEvent_t ev0 = evs.e[0], ev1 = evs.e[1], ev2 = evs.e[2];
         HIP_CHECK(hipEventRecord(ev0, st));
 
         // first model input: scale_model_input(concat(latents, latents), t0)  (:273-278)
@@ -727,7 +732,6 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             stats->unet_calls = unet_calls; stats->unet_ms = a; stats->vae_ms = b; stats->total_ms = a + b;
             stats->host_enqueue_ms = (float)enqueue_ms;
         }
-        (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1); (void)hipEventDestroy(ev2);
     });
 }
 
