@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Randomised model-level parity sweep: random small UNet / VAE-decoder architectures (widths, depth, attention placement, head
+counts, linear vs conv projections, text width), written as model dirs by modelgen (raw-export dialect, or the optimizer-fused one),
+loaded by the product loader, run at random latent sizes / text lengths / batch sizes and compared with the CPU oracle.
+Bars: north_star's (rel-L2 <= 1e-2 for the UNet, PSNR >= 35 dB for the decoder).  usage: python tools/fuzz_models.py [n] [seed]"""
+import os
+import shutil
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from diffusers_amd import modelgen
+from diffusers_amd.pipeline import StableDiffusionPipeline
+from oracle import model_dir, unet_ref
+
+
+def rel_l2(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def psnr(a, b):
+    mse = float(np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2))
+    return 10 * np.log10(1.0 / max(mse, 1e-20))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = np.random.default_rng(seed)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    bad = 0
+    for it in range(n):
+        levels = int(rng.integers(1, 5))
+        widths = tuple(int(rng.choice([32, 64, 96, 128, 160])) for _ in range(levels))
+        attn = tuple(bool(rng.random() < 0.7) for _ in range(levels))
+        per_level = rng.random() < 0.4
+        heads = tuple(int(rng.choice([h for h in (1, 2, 4, 8) if w % h == 0 and (w // h) % 8 == 0] or [1])) for w in widths)
+        ucfg = modelgen.unet_config(block_out_channels=widths, layers_per_block=int(rng.integers(1, 3)), down_attn=attn,
+                                    cross_attention_dim=int(rng.choice([32, 64, 96])),
+                                    num_heads=heads if per_level else int(np.gcd.reduce([h for h in heads])),
+                                    use_linear_projection=bool(rng.random() < 0.5))
+        vlev = int(rng.integers(1, 4))
+        vcfg = modelgen.vae_config(block_out_channels=tuple(int(rng.choice([32, 64, 128])) for _ in range(vlev)),
+                                   layers_per_block=int(rng.integers(1, 3)))
+        fused = bool(rng.random() < 0.4)
+        d = tempfile.mkdtemp(prefix="sde_fuzz_")
+        try:
+            wseed, dt = int(rng.integers(1 << 30)), (np.float16 if rng.random() < 0.3 else np.float32)
+            modelgen.write_model_dir(d, ucfg, vcfg, seed=wseed, dtype=dt)              # raw export: what the oracle's binder reads
+            eng_dir = d
+            if fused:                                                                   # same weights in the optimizer's dialect
+                eng_dir = os.path.join(d, "fused")
+                modelgen.write_model_dir(eng_dir, ucfg, vcfg, seed=wseed, dtype=dt, fused=True, nv=bool(rng.random() < 0.5))
+            pipe = StableDiffusionPipeline(eng_dir)
+            uw, oc = model_dir.load_unet(d)
+            uw = {k: torch.from_numpy(v.astype(np.float32)) for k, v in uw.items()}
+            N_, h, w, S = int(rng.integers(1, 4)), int(rng.integers(1, 25)), int(rng.integers(1, 25)), int(rng.choice([77, 152, 227, 9]))
+            x = rng.standard_normal((N_, 4, h, w)).astype(np.float32)
+            ehs = (rng.standard_normal((N_, S, ucfg["cross_attention_dim"])) * 0.5).astype(np.float32)
+            t = float(rng.choice([999.0, 500.5, 0.0, 37.2]))
+            with torch.no_grad():
+                ref = unet_ref.unet_forward(uw, oc, torch.from_numpy(x), t, torch.from_numpy(ehs)).numpy()
+            got = pipe.unet(x, t, ehs)
+            e1 = rel_l2(got, ref)
+            tag = f"unet widths={widths} attn={attn} heads={ucfg['num_heads']} lin={ucfg['use_linear_projection']} lpb={ucfg['layers_per_block']} " \
+                  f"ctx={ucfg['cross_attention_dim']} fused={fused} N={N_} {h}x{w} S={S}"
+            ok = np.isfinite(got).all() and e1 < 1e-2
+            if not fused:      # the fused VAE dialect drops the attention biases (REFERENCE_QUIRK): compare raw exports only
+                vw, vc = model_dir.load_vae_decoder(d)
+                vw = {k: torch.from_numpy(v.astype(np.float32)) for k, v in vw.items()}
+                lat = rng.standard_normal((N_, 4, h, w)).astype(np.float32)
+                with torch.no_grad():
+                    rimg = unet_ref.decode_latents(vw, vc, torch.from_numpy(lat)).numpy()
+                p = psnr(pipe.decode_latents(lat), rimg)
+                tag += f" | vae {vcfg['block_out_channels']} lpb={vcfg['layers_per_block']} psnr={p:.1f}"
+                ok = ok and p >= 35.0
+            print(("ok  " if ok else "MISS") + f" {e1:.2e} {tag}", flush=True)
+            bad += 0 if ok else 1
+            pipe.close()
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    print(f"{n} models, {bad} misses")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
