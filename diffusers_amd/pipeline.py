@@ -56,7 +56,10 @@ class StableDiffusionPipeline:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:   # interpreter shutdown: the ctypes module may already be torn down
+            pass
 
     def info(self) -> _lib.ModelInfo:
         mi = _lib.ModelInfo()

@@ -62,7 +62,10 @@ class DiffusionScheduler:
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
-            _lib.lib().sde_scheduler_destroy(h)
+            try:
+                _lib.lib().sde_scheduler_destroy(h)
+            except Exception:   # interpreter shutdown: the ctypes module may already be torn down
+                pass
             self._h = None
 
     # --- trait methods
