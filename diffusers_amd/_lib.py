@@ -32,7 +32,8 @@ class SchedCfg(C.Structure):
     _fields_ = [("num_train_timesteps", C.c_int), ("beta_start", C.c_float), ("beta_end", C.c_float),
                 ("beta_schedule", C.c_int), ("prediction_type", C.c_int), ("reference_quirks", C.c_int),
                 ("solver_order", C.c_int), ("lower_order_final", C.c_int), ("clip_sample", C.c_int),
-                ("set_alpha_to_one", C.c_int), ("steps_offset", C.c_int), ("variance_type", C.c_int)]
+                ("set_alpha_to_one", C.c_int), ("steps_offset", C.c_int), ("variance_type", C.c_int),
+                ("algorithm_type", C.c_int), ("solver_type", C.c_int)]
 
 
 CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_float, c_float_p, C.c_size_t, C.c_void_p)
@@ -47,7 +48,8 @@ class Txt2ImgOpts(C.Structure):
                 ("skip_decode", C.c_int), ("callback_kind", C.c_int), ("callback_frequency", C.c_int),
                 ("callback", CALLBACK), ("callback_user", C.c_void_p), ("noise_pred_out", C.c_void_p),
                 ("latents_out", C.c_void_p), ("final_latents_out", C.c_void_p),
-                ("cfg_half", C.c_int), ("exchange", EXCHANGE), ("exchange_user", C.c_void_p)]
+                ("cfg_half", C.c_int), ("exchange", EXCHANGE), ("exchange_user", C.c_void_p),
+                ("trace_rows", C.c_int), ("step_noise_rows", C.c_int)]
 
 
 class RunStats(C.Structure):

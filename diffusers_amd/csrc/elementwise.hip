@@ -197,7 +197,7 @@ struct StepDev {
     float guidance;
     const float* rescale_factor;
     const float* model_out; float* latents; const float* noise;
-    float c[8]; int clip;
+    float c[12]; int clip, dpm_algo;
     float* hist[4]; int nhist; float lms_c[4];
     float next_scale; half_t* next_input; int Cpad;
     float* eps_out;
@@ -232,18 +232,37 @@ __global__ void cfg_step_kernel(StepDev a)
             prev = prev + a.noise[i] * a.c[2];
         } break;
         case STEP_DPM1:
-        case STEP_DPM2M: {   // dpm_solver_multistep.rs:211-257 ; c0 = alpha_t, c1 = sigma_t, c2 = sigma_p/sigma_c, c3 = alpha_p*(exp(-h)-1)
-            float x0;
-            if (a.pred == SDE_PRED_EPSILON) x0 = (s - a.c[1] * e) / a.c[0];
-            else if (a.pred == SDE_PRED_SAMPLE) x0 = e;
-            else x0 = a.c[0] * s - a.c[1] * e;
-            if (a.kind == STEP_DPM1) prev = a.c[2] * s - a.c[3] * x0;
-            else {           // :259-278 midpoint ; c4 = 1/r0, c5 = 0.5*c3 ; hist[0] = previous x0
-                float m1 = a.hist[0][i];
-                float d1 = a.c[4] * (x0 - m1);
-                prev = a.c[2] * s - a.c[3] * x0 - a.c[5] * d1;
+        case STEP_DPM2M:
+        case STEP_DPM3M: {   // dpm_solver_multistep.rs:211-326 ; c0 = alpha_s, c1 = sigma_s (current timestep), c2 multiplies the sample,
+                             // c3 multiplies the converted output m0 (D++: sigma_t/sigma_s, alpha_t*(exp(-h)-1); DPMSolver: alpha_t/alpha_s,
+                             // sigma_t*(exp(h)-1), :254-255)
+            float m0;
+            if (a.dpm_algo == 0) {                     // DPMSolverPlusPlus: x0 prediction (:213-231)
+                if (a.pred == SDE_PRED_EPSILON) m0 = (s - a.c[1] * e) / a.c[0];
+                else if (a.pred == SDE_PRED_SAMPLE) m0 = e;
+                else m0 = a.c[0] * s - a.c[1] * e;
+            } else {                                   // DPMSolver: noise prediction (:232-244)
+                if (a.pred == SDE_PRED_EPSILON) m0 = e;
+                else if (a.pred == SDE_PRED_SAMPLE) m0 = (s - a.c[0] * e) / a.c[1];
+                else m0 = a.c[0] * e + a.c[1] * s;
             }
-            if (a.nhist > 0) a.hist[1][i] = x0;  // host swaps hist[0] <-> hist[1] after every step
+            if (a.kind == STEP_DPM1) prev = a.c[2] * s - a.c[3] * m0;
+            else if (a.kind == STEP_DPM2M) {
+                // :259-285 ; c4 = 1/r0 ; hist[0] = m1.  c5 = the d1 coefficient as the reference SUBTRACTS it (Midpoint 0.5*c3;
+                // DPMSolver Heun sigma_t*((exp(h)-1)/h - 1); D++ Heun adds its term, so the host passes it negated: x - (-c)*d == x + c*d)
+                float m1 = a.hist[0][i];
+                float d1 = a.c[4] * (m0 - m1);
+                prev = a.c[2] * s - a.c[3] * m0 - a.c[5] * d1;
+            } else {
+                // :288-326 ; hist[0] = m1, hist[1] = m2 ; c4 = 1/r0, c6 = 1/r1, c7 = r0/(r0+r1), c8 = 1/(r0+r1), c5 / c9 = d1 / d2 coefficients
+                // (c5 negated by the host for D++, whose d1 term is added)
+                float m1 = a.hist[0][i], m2 = a.hist[1][i];
+                float d10 = a.c[4] * (m0 - m1), d11 = a.c[6] * (m1 - m2);
+                float d1 = d10 + a.c[7] * (d10 - d11);
+                float d2 = a.c[8] * (d10 - d11);
+                prev = a.c[2] * s - a.c[3] * m0 - a.c[5] * d1 - a.c[9] * d2;
+            }
+            if (a.nhist > 0) a.hist[a.nhist - 1][i] = m0;  // the host rotates the buffers after every step (write slot -> hist[0])
         } break;
         case STEP_DDIM: {    // ddim.rs:210-238 ; c0 = sqrt(alpha_t), c1 = sqrt(beta_t), c2 = sqrt(alpha_prev), c3 = sqrt(1 - alpha_prev - std^2)
             float mo = e, x0;
@@ -286,8 +305,8 @@ void launch_cfg_step(const LaunchCtx& ctx, const StepArgs& s)
     StepDev a;
     a.kind = s.kind; a.pred = s.pred; a.B = s.B; a.C = s.C; a.HW = s.H * s.W; a.cfg = s.cfg; a.guidance = s.guidance;
     a.rescale_factor = s.rescale_factor; a.model_out = s.model_out; a.latents = s.latents; a.noise = s.noise;
-    for (int i = 0; i < 8; ++i) a.c[i] = s.c[i];
-    a.clip = s.clip;
+    for (int i = 0; i < 12; ++i) a.c[i] = s.c[i];
+    a.clip = s.clip; a.dpm_algo = s.dpm_algo;
     for (int i = 0; i < 4; ++i) { a.hist[i] = s.hist[i]; a.lms_c[i] = s.lms_c[i]; }
     a.nhist = s.nhist; a.next_scale = s.next_input_scale; a.next_input = s.next_input; a.Cpad = s.Cpad; a.eps_out = s.eps_out;
     SDE_REQUIRE(!((s.kind == STEP_EULER_A) && !s.noise), SDE_ERR_INVALID_ARGUMENT, "cfg_step: Euler-a needs a noise tensor");

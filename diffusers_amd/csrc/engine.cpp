@@ -5,7 +5,9 @@
 #include <cmath>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <random>
+#include <thread>
 
 #include "model.h"
 #include "rng.h"
@@ -87,6 +89,40 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
 
+// page-locked host staging (async copies that really are asynchronous)
+struct PinnedBuf {
+    void* p = nullptr; size_t cap = 0;
+    void ensure(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        if (p) { HIP_CHECK(hipDeviceSynchronize()); HIP_CHECK(hipHostFree(p)); p = nullptr; cap = 0; }
+        HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocDefault));
+        cap = bytes;
+    }
+    template <typename T> T* as() { return (T*)p; }
+    ~PinnedBuf() { if (p) (void)hipHostFree(p); }
+};
+
+// A second stream with everything a VAE decode needs for itself (arena, split-K workspace, staging), so that preview
+// callbacks (StableDiffusionCallback::{Latents, Decoded, ApproximateDecoded}, mod.rs:41-86) run beside the denoise stream
+// instead of stalling it.  Created on first use.
+struct PreviewLane {
+    hipStream_t stream = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;   // ready: latents of the step are final (main stream) ; done: payload is in `host`
+    LaunchCtx ctx;
+    Arena arena;
+    DevBuf arena_buf, vae_in, splitk_ws, images;
+    PinnedBuf host;
+    long long key = -1;
+    size_t peak = 0;
+    ~PreviewLane()
+    {
+        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (ready) (void)hipEventDestroy(ready);
+        if (done) (void)hipEventDestroy(done);
+    }
+};
+
 struct sde_engine {
     int device = 0;
     sde_engine_opts opts{};
@@ -99,9 +135,12 @@ struct sde_engine {
     VaeDecoderModel vae;
     bool has_unet = false, has_vae = false;
     Arena arena;
-    DevBuf arena_buf, zeros, splitk_ws, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps;
+    DevBuf arena_buf, zeros, splitk_ws, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps, rescale_ws;
+    PinnedBuf noise_host;
+    std::unique_ptr<PreviewLane> preview;
     std::vector<half_t*> kv_ptrs;
     std::mutex mu;  // one forward at a time per engine (reference: Session is Send+Sync; here calls serialize)
+    std::atomic<std::thread::id> owner{std::thread::id()};  // thread inside a locked call (re-entry from a callback is refused)
     // cached arena sizing
     long long unet_key = -1, vae_key = -1;
     size_t unet_peak = 0, vae_peak = 0;
@@ -114,6 +153,22 @@ struct sde_engine {
 };
 
 static void engine_activate(sde_engine* e) { HIP_CHECK(hipSetDevice(e->device)); }
+
+// Serialises calls on one engine.  Callbacks and the exchange hook run with the lock held (sdengine.h): a call back into the
+// same engine from inside one is an error status, not a deadlock on the non-recursive mutex.
+struct EngineLock {
+    sde_engine* e;
+    explicit EngineLock(sde_engine* eng) : e(eng)
+    {
+        SDE_REQUIRE(e->owner.load() != std::this_thread::get_id(), SDE_ERR_INVALID_ARGUMENT,
+                    "engine re-entered from one of its own callbacks (callbacks must not call back into the engine that runs them)");
+        e->mu.lock();
+        e->owner.store(std::this_thread::get_id());
+    }
+    ~EngineLock() { e->owner.store(std::thread::id()); e->mu.unlock(); }
+    EngineLock(const EngineLock&) = delete;
+    EngineLock& operator=(const EngineLock&) = delete;
+};
 
 static void ensure_arena(sde_engine* e, size_t bytes)
 {
@@ -185,6 +240,46 @@ static void decode_dev(sde_engine* e, const float* d_latents, int B, int h, int 
         launch_pack_nchw(e->ctx, d_latents + (size_t)b0 * e->vae.latent_channels * h * w, e->vae_in.as<half_t>(), nb, e->vae.latent_channels, h, w,
                          VaeDecoderModel::kInPad, scale);
         vae_run(e, e->vae_in.as<half_t>(), nb, h, w, epi, d_out + (size_t)b0 * e->vae.out_channels * h * up * w * up);
+    }
+}
+
+static PreviewLane& preview_lane(sde_engine* e)
+{
+    if (!e->preview) {
+        std::unique_ptr<PreviewLane> L(new PreviewLane());
+        HIP_CHECK(hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&L->ready, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+        L->ctx = e->ctx; L->ctx.stream = L->stream; L->ctx.prof = nullptr;
+        L->splitk_ws.ensure((size_t)64 << 20);
+        L->ctx.splitk_ws = L->splitk_ws.as<float>(); L->ctx.splitk_ws_bytes = L->splitk_ws.cap;
+        e->preview = std::move(L);
+    }
+    return *e->preview;
+}
+
+// decode_latents on the preview lane (its own stream, arena and workspaces): same kernels, same arithmetic as decode_dev
+static void decode_on_lane(sde_engine* e, PreviewLane& L, const float* d_latents, int B, int h, int w, float* d_out)
+{
+    SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "Decoded callback needs the VAE decoder");
+    const int chunk = std::max(1, std::min(B, 8)), up = e->vae.upscale();
+    const long long key = ((long long)chunk << 40) ^ ((long long)h << 20) ^ w;
+    if (key != L.key) {
+        Arena dry; dry.dry = true;
+        Exec dx{L.ctx, &dry};
+        e->vae.forward(dx, nullptr, chunk, h, w, EPI_IMAGE, nullptr);
+        L.peak = dry.peak; L.key = key;
+    }
+    if (L.peak > L.arena_buf.cap) { HIP_CHECK(hipStreamSynchronize(L.stream)); L.arena_buf.ensure(L.peak + (L.peak >> 3)); }
+    L.arena.base = L.arena_buf.as<char>(); L.arena.cap = L.arena_buf.cap; L.arena.dry = false;
+    L.vae_in.ensure((size_t)chunk * h * w * VaeDecoderModel::kInPad * sizeof(half_t));
+    for (int b0 = 0; b0 < B; b0 += chunk) {
+        const int nb = std::min(chunk, B - b0);
+        launch_pack_nchw(L.ctx, d_latents + (size_t)b0 * e->vae.latent_channels * h * w, L.vae_in.as<half_t>(), nb, e->vae.latent_channels, h, w,
+                         VaeDecoderModel::kInPad, 1.0f / 0.18215f);
+        L.arena.off = 0; L.arena.peak = 0;
+        Exec ex{L.ctx, &L.arena};
+        e->vae.forward(ex, L.vae_in.as<half_t>(), nb, h, w, EPI_IMAGE, d_out + (size_t)b0 * e->vae.out_channels * h * up * w * up);
     }
 }
 
@@ -318,21 +413,28 @@ static void check_unet_args(const sde_engine* e, const void* sample, int N, int 
                 "encoder_hidden_states width " + std::to_string(D) + " != cross_attention_dim " + std::to_string(e->unet.ctx_dim));
 }
 
+// caller holds the engine lock
+static void unet_forward_dev_locked(sde_engine* e, const float* d_sample, int N, int h, int w, float timestep, const float* d_ehs, int S, int D,
+                                    float* d_out)
+{
+    const int Cp = UNetModel::kInPad;
+    e->x_packed.ensure((size_t)N * h * w * Cp * sizeof(half_t));
+    e->ehs_h.ensure((size_t)N * S * D * sizeof(half_t));
+    setup_kv(e, N, S);
+    launch_pack_nchw(e->ctx, d_sample, e->x_packed.as<half_t>(), N, e->unet.in_channels, h, w, Cp, 1.0f);
+    launch_f32_to_f16(e->ctx, d_ehs, e->ehs_h.as<half_t>(), (int64_t)N * S * D);
+    unet_run(e, e->x_packed.as<half_t>(), N, h, w, timestep, e->ehs_h.as<half_t>(), S, true, d_out);
+    HIP_CHECK(hipStreamSynchronize(e->stream));
+}
+
 sde_status sde_unet_forward_dev(sde_engine* e, const float* d_sample, int N, int h, int w, float timestep, const float* d_ehs, int S, int D,
                                 float* d_out)
 {
     return guarded([&] {
         check_unet_args(e, d_sample, N, h, w, d_ehs, S, D, d_out);
-        std::lock_guard<std::mutex> lk(e->mu);
+        EngineLock lk(e);
         engine_activate(e);
-        const int Cp = UNetModel::kInPad;
-        e->x_packed.ensure((size_t)N * h * w * Cp * sizeof(half_t));
-        e->ehs_h.ensure((size_t)N * S * D * sizeof(half_t));
-        setup_kv(e, N, S);
-        launch_pack_nchw(e->ctx, d_sample, e->x_packed.as<half_t>(), N, e->unet.in_channels, h, w, Cp, 1.0f);
-        launch_f32_to_f16(e->ctx, d_ehs, e->ehs_h.as<half_t>(), (int64_t)N * S * D);
-        unet_run(e, e->x_packed.as<half_t>(), N, h, w, timestep, e->ehs_h.as<half_t>(), S, true, d_out);
-        HIP_CHECK(hipStreamSynchronize(e->stream));
+        unet_forward_dev_locked(e, d_sample, N, h, w, timestep, d_ehs, S, D, d_out);
     });
 }
 
@@ -340,19 +442,15 @@ sde_status sde_unet_forward(sde_engine* e, const float* sample, int N, int h, in
 {
     return guarded([&] {
         check_unet_args(e, sample, N, h, w, ehs, S, D, out);
-        size_t ns, ne;
-        {
-            std::lock_guard<std::mutex> lk(e->mu);
-            engine_activate(e);
-            ns = (size_t)N * e->unet.in_channels * h * w; ne = (size_t)N * S * D;
-            e->scratch_f.ensure((ns + ne + (size_t)N * e->unet.out_channels * h * w) * sizeof(float));
-            HIP_CHECK(hipMemcpy(e->scratch_f.p, sample, ns * 4, hipMemcpyHostToDevice));
-            HIP_CHECK(hipMemcpy(e->scratch_f.as<float>() + ns, ehs, ne * 4, hipMemcpyHostToDevice));
-        }
+        EngineLock lk(e);   // held across upload, forward and download: the staging buffer is this call's alone
+        engine_activate(e);
+        const size_t ns = (size_t)N * e->unet.in_channels * h * w, ne = (size_t)N * S * D, no = (size_t)N * e->unet.out_channels * h * w;
+        e->scratch_f.ensure((ns + ne + no) * sizeof(float));
         float* d = e->scratch_f.as<float>();
-        sde_status st = sde_unet_forward_dev(e, d, N, h, w, timestep, d + ns, S, D, d + ns + ne);
-        if (st != SDE_OK) sde_fail(st, g_last_error);
-        HIP_CHECK(hipMemcpy(out, d + ns + ne, (size_t)N * e->unet.out_channels * h * w * 4, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(d, sample, ns * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(d + ns, ehs, ne * 4, hipMemcpyHostToDevice));
+        unet_forward_dev_locked(e, d, N, h, w, timestep, d + ns, S, D, d + ns + ne);
+        HIP_CHECK(hipMemcpy(out, d + ns + ne, no * 4, hipMemcpyDeviceToHost));
     });
 }
 
@@ -362,7 +460,7 @@ static sde_status vae_common(sde_engine* e, const float* latents, int B, int h, 
         SDE_REQUIRE(e && latents && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
         SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "engine was created without a VAE decoder");
         SDE_REQUIRE(B > 0 && h > 0 && w > 0, SDE_ERR_INVALID_ARGUMENT, "empty tensor");
-        std::lock_guard<std::mutex> lk(e->mu);
+        EngineLock lk(e);
         engine_activate(e);
         const int up = e->vae.upscale();
         const size_t nl = (size_t)B * e->vae.latent_channels * h * w, no = (size_t)B * e->vae.out_channels * h * up * w * up;
@@ -387,7 +485,7 @@ sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, in
 {
     return guarded([&] {
         SDE_REQUIRE(e && latents && images && B > 0 && h > 0 && w > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
-        std::lock_guard<std::mutex> lk(e->mu);
+        EngineLock lk(e);
         engine_activate(e);
         const size_t nl = (size_t)B * 4 * h * w, no = (size_t)B * h * w * 3;
         e->latents.ensure(nl * 4); e->images.ensure(no * 4);
@@ -408,6 +506,7 @@ void sde_sched_cfg_default(int kind, sde_sched_cfg* c)
     c->solver_order = 2; c->lower_order_final = 1;                 // dpm_solver_multistep.rs:80-92
     c->clip_sample = kind == SDE_SCHED_DDIM ? 1 : 0;               // ddim.rs:59-67 ; ddpm.rs:40 (derive Default => false)
     c->set_alpha_to_one = 1; c->steps_offset = 0; c->variance_type = 0;
+    c->algorithm_type = SDE_DPM_SOLVER_PP; c->solver_type = SDE_DPM_MIDPOINT;   // dpm_solver_multistep.rs:87-88
 }
 void sde_sched_cfg_sd_v1(int kind, sde_sched_cfg* c)
 {
@@ -492,8 +591,8 @@ sde_status sde_scheduler_step(sde_scheduler* s, const float* model_output, float
         StepArgs a;
         a.kind = p.kind; a.pred = p.pred; a.B = 1; a.C = 1; a.H = 1; a.W = (int)n; a.cfg = 0;
         a.model_out = t.up(model_output, n); a.latents = t.up(sample, n); a.noise = p.needs_noise ? t.up(noise, n) : nullptr;
-        for (int i = 0; i < 8; ++i) a.c[i] = p.c[i];
-        a.clip = p.clip; a.nhist = p.nhist;
+        for (int i = 0; i < 12; ++i) a.c[i] = p.c[i];
+        a.clip = p.clip; a.nhist = p.nhist; a.dpm_algo = p.dpm_algo;
         for (int i = 0; i < 4; ++i) a.lms_c[i] = p.lms_c[i];
         if (p.nhist > 0 || s->kind == SDE_SCHED_LMS) {
             if (s->mirror_hist_n != n) {
@@ -506,8 +605,7 @@ sde_status sde_scheduler_step(sde_scheduler* s, const float* model_output, float
         }
         launch_cfg_step(ctx, a);
         HIP_CHECK(hipMemcpy(prev_sample, a.latents, n * 4, hipMemcpyDeviceToHost));
-        if (s->kind == SDE_SCHED_DPMPP && p.nhist > 0) std::swap(s->mirror_hist[0], s->mirror_hist[1]);
-        if (s->kind == SDE_SCHED_LMS) std::rotate(s->mirror_hist.begin(), s->mirror_hist.begin() + 3, s->mirror_hist.end());  // [0] becomes the free slot
+        if (!s->mirror_hist.empty()) s->rotate_history(p, s->mirror_hist.data());
         s->advance(p);
     });
 }
@@ -548,7 +646,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         SDE_REQUIRE(o->skip_decode || images_out, SDE_ERR_INVALID_ARGUMENT, "images_out is null");
         SDE_REQUIRE(o->batch_size > 0 && o->steps > 0 && o->ehs && o->S > 0, SDE_ERR_INVALID_ARGUMENT, "bad batch/steps/embeddings");
         SDE_REQUIRE(o->D == e->unet.ctx_dim, SDE_ERR_INVALID_ARGUMENT, "text embedding width does not match the UNet's cross_attention_dim");
-        std::lock_guard<std::mutex> lk(e->mu);
+        EngineLock lk(e);
         engine_activate(e);
         const int B = o->batch_size, h = o->height / 8, w = o->width / 8, S = o->S, D = o->D, C = e->unet.in_channels;
         const bool cfg = o->guidance_scale > 1.0f;  // :258
@@ -572,6 +670,19 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         const std::vector<float> ts = sch->timesteps;         // :269
         const int nt = (int)ts.size();
         SDE_REQUIRE(nt > 0, SDE_ERR_SCHEDULER, "scheduler produced no timesteps");
+        // per-timestep caller buffers: nt is the scheduler's count, not `steps` (DDPM: ceil(T / (T / steps)), ddpm.rs:181)
+        if (o->noise_pred_out || o->latents_out) {
+            const int rows = o->trace_rows > 0 ? o->trace_rows : o->steps;
+            SDE_REQUIRE(nt <= rows, SDE_ERR_INVALID_ARGUMENT,
+                        "noise_pred_out / latents_out hold " + std::to_string(rows) + " rows but this scheduler runs " + std::to_string(nt) +
+                            " timesteps (set trace_rows from sde_scheduler_num_timesteps)");
+        }
+        if (o->step_noise) {
+            const int rows = o->step_noise_rows > 0 ? o->step_noise_rows : o->steps;
+            SDE_REQUIRE(nt <= rows, SDE_ERR_INVALID_ARGUMENT,
+                        "step_noise holds " + std::to_string(rows) + " rows but this scheduler runs " + std::to_string(nt) +
+                            " timesteps (set step_noise_rows from sde_scheduler_num_timesteps)");
+        }
         long long num_warmup = (long long)nt - (long long)o->steps * 1;  // :270 ; negative == usize wrap-around in release builds
         if (num_warmup < 0) num_warmup = (1LL << 62);
 
@@ -604,7 +715,14 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         float* hist[4] = {e->hist[0].as<float>(), e->hist[1].as<float>(), e->hist[2].as<float>(), e->hist[3].as<float>()};
         const bool want_taps = o->noise_pred_out != nullptr;
         if (want_taps) e->taps.ensure(per * 4);
-        if (o->has_rescale_cfg && cfg) e->scratch_f.ensure(4096);
+        if (o->has_rescale_cfg && cfg) e->rescale_ws.ensure(4096);   // its own buffer: scratch_f belongs to sde_unet_forward
+        // Scheduler noise (Euler-a, DDPM): draw t's tensor on the host while the GPU is inside UNet call t, into a slot of its own in
+        // page-locked memory, and copy it with the stream -- no per-step synchronisation (all nt x per draws come from one
+        // sequential stream, seed + 31337, so they are drawn in step order).  Very long runs fall back to a two-slot ring.
+        const bool host_noise = !(o->step_noise && o->buffers_on_device);
+        const size_t noise_slots = (size_t)nt * per * 4 <= ((size_t)512 << 20) ? (size_t)nt : 2;
+        hipEvent_t noise_ev[2] = {nullptr, nullptr};
+        struct NoiseEvents { hipEvent_t* e; ~NoiseEvents() { for (int k = 0; k < 2; ++k) if (e[k]) (void)hipEventDestroy(e[k]); } } noise_evs{noise_ev};
 
         struct Events {   // destroyed on every exit path (an error inside the loop throws past the end of this function)
             hipEvent_t e[3] = {nullptr, nullptr, nullptr};
@@ -621,13 +739,25 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         }
         int unet_calls = 0;
         double enqueue_ms = 0.0;
-        std::vector<float> cb_buf;
+        struct LaneDrain {   // nothing of the preview lane may outlive the call, whichever way it ends
+            sde_engine* e;
+            ~LaneDrain() { if (e->preview) (void)hipStreamSynchronize(e->preview->stream); }
+        } lane_drain{e};
+        bool pending_cb = false, stopped = false;   // a payload callback produced at step pending_i, not yet delivered
+        int pending_i = 0; float pending_t = 0.f; size_t pending_n = 0;
         for (int i = 0; i < nt; ++i) {
             const float t = ts[(size_t)i];
             const auto tq0 = std::chrono::steady_clock::now();
             unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, e->ehs_h.as<half_t>() + half_off * B * S * D, S, i == 0,
                      e->model_out.as<float>() + half_off * per);                                             // :283
             enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
+            if (pending_cb) {
+                // deliver step i-1's payload while the GPU works on UNet call i.  `false` -> break (:319-321): the UNet call just
+                // enqueued is abandoned (it only wrote model_out), latents are still those of step i-1, as in the reference.
+                HIP_CHECK(hipEventSynchronize(e->preview->done));
+                pending_cb = false;
+                if (!o->callback(pending_i, pending_t, e->preview->host.as<float>(), pending_n, o->callback_user)) { stopped = true; break; }
+            }
             ++unet_calls;
             if (half) {
                 HIP_CHECK(hipStreamSynchronize(st));
@@ -639,23 +769,30 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             StepArgs a;
             a.kind = p.kind; a.pred = p.pred; a.B = B; a.C = C; a.H = h; a.W = w; a.cfg = cfg ? 1 : 0; a.guidance = o->guidance_scale;
             a.model_out = e->model_out.as<float>(); a.latents = d_lat;
-            for (int k = 0; k < 8; ++k) a.c[k] = p.c[k];
-            a.clip = p.clip; a.nhist = p.nhist;
+            for (int k = 0; k < 12; ++k) a.c[k] = p.c[k];
+            a.clip = p.clip; a.nhist = p.nhist; a.dpm_algo = p.dpm_algo;
             for (int k = 0; k < 4; ++k) { a.lms_c[k] = p.lms_c[k]; a.hist[k] = hist[k]; }
             if (p.needs_noise) {
-                e->noise.ensure(per * 4);
-                if (o->step_noise && o->buffers_on_device) a.noise = o->step_noise + (size_t)i * per;
+                if (!host_noise) a.noise = o->step_noise + (size_t)i * per;
                 else {
-                    const float* src;
-                    if (o->step_noise) src = o->step_noise + (size_t)i * per;
-                    else { host_tmp.resize(per); sde::fill_standard_normal(sched_rng, host_tmp.data(), per); src = host_tmp.data(); }
-                    HIP_CHECK(hipMemcpyAsync(e->noise.p, src, per * 4, hipMemcpyHostToDevice, st));
-                    HIP_CHECK(hipStreamSynchronize(st));
-                    a.noise = e->noise.as<float>();
+                    e->noise.ensure(noise_slots * per * 4);
+                    e->noise_host.ensure(noise_slots * per * 4);
+                    const size_t slot = noise_slots == (size_t)nt ? (size_t)i : (size_t)(i & 1);
+                    float* hbuf = e->noise_host.as<float>() + slot * per;
+                    if (noise_slots == 2) {   // ring: the copy that last read this slot must have finished
+                        if (noise_ev[slot]) HIP_CHECK(hipEventSynchronize(noise_ev[slot]));
+                        else HIP_CHECK(hipEventCreateWithFlags(&noise_ev[slot], hipEventDisableTiming));
+                    }
+                    if (o->step_noise) memcpy(hbuf, o->step_noise + (size_t)i * per, per * 4);
+                    else sde::fill_standard_normal(sched_rng, hbuf, per);
+                    float* dbuf = e->noise.as<float>() + slot * per;
+                    HIP_CHECK(hipMemcpyAsync(dbuf, hbuf, per * 4, hipMemcpyHostToDevice, st));
+                    if (noise_slots == 2) HIP_CHECK(hipEventRecord(noise_ev[slot], st));
+                    a.noise = dbuf;
                 }
             }
             if (o->has_rescale_cfg && cfg) {
-                float* ws = e->scratch_f.as<float>();
+                float* ws = e->rescale_ws.as<float>();
                 launch_cfg_rescale_factor(e->ctx, e->model_out.as<float>(), B, (int64_t)per, o->guidance_scale, o->rescale_cfg, ws + 16, ws);
                 a.rescale_factor = ws;
             }
@@ -666,42 +803,44 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             if (want_taps) a.eps_out = e->taps.as<float>();
             launch_cfg_step(e->ctx, a);                                                                  // :288-304
             sch->advance(p);
-            if (sch->kind == SDE_SCHED_DPMPP && p.nhist > 0) std::swap(hist[0], hist[1]);
-            if (sch->kind == SDE_SCHED_LMS) std::rotate(hist, hist + 3, hist + 4);
+            sch->rotate_history(p, hist);
             if (want_taps) HIP_CHECK(hipMemcpyAsync(o->noise_pred_out + (size_t)i * per, e->taps.p, per * 4, hipMemcpyDeviceToHost, st));
             if (o->latents_out) HIP_CHECK(hipMemcpyAsync(o->latents_out + (size_t)i * per, d_lat, per * 4, hipMemcpyDeviceToHost, st));
             if (want_taps || o->latents_out) HIP_CHECK(hipStreamSynchronize(st));
-            // callbacks (:306-323)
+            // callbacks (:306-323).  Progress needs nothing from the GPU and is called at once.  The kinds that hand over a tensor
+            // are produced on the preview lane (second stream) from the latents this step left, and DELIVERED after the next UNet
+            // call has been enqueued, so the denoise stream never waits for the copy, the VAE or the user's code; the callback
+            // still sees step i's latents, in step order, on the caller's thread, before step i + 1's scheduler update.
             if (o->callback && o->callback_kind != SDE_CB_NONE) {
                 const int freq = std::max(1, o->callback_frequency);
                 if (i == nt - 1 || ((long long)(i + 1) > num_warmup && (i + 1) % 1 == 0)) {
-                    int keep = 1;
-                    if (o->callback_kind == SDE_CB_PROGRESS && i % freq == 0) keep = o->callback(i, t, nullptr, 0, o->callback_user);
-                    else if (o->callback_kind == SDE_CB_LATENTS && i % freq == 0) {
-                        cb_buf.resize(per);
-                        HIP_CHECK(hipMemcpyAsync(cb_buf.data(), d_lat, per * 4, hipMemcpyDeviceToHost, st));
-                        HIP_CHECK(hipStreamSynchronize(st));
-                        keep = o->callback(i, t, cb_buf.data(), per, o->callback_user);
-                    } else if (o->callback_kind == SDE_CB_DECODED && i != 0 && i % freq == 0) {
-                        SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "Decoded callback needs the VAE decoder");
-                        const int up = e->vae.upscale();
-                        const size_t no = (size_t)B * h * up * w * up * e->vae.out_channels;
-                        e->images.ensure(no * 4);
-                        decode_dev(e, d_lat, B, h, w, EPI_IMAGE, e->images.as<float>());
-                        cb_buf.resize(no);
-                        HIP_CHECK(hipMemcpyAsync(cb_buf.data(), e->images.p, no * 4, hipMemcpyDeviceToHost, st));
-                        HIP_CHECK(hipStreamSynchronize(st));
-                        keep = o->callback(i, t, cb_buf.data(), no, o->callback_user);
-                    } else if (o->callback_kind == SDE_CB_APPROXIMATE && i != 0 && i % freq == 0) {
-                        const size_t no = (size_t)B * h * w * 3;
-                        e->images.ensure(no * 4);
-                        launch_approx_decode(e->ctx, d_lat, e->images.as<float>(), B, h, w);
-                        cb_buf.resize(no);
-                        HIP_CHECK(hipMemcpyAsync(cb_buf.data(), e->images.p, no * 4, hipMemcpyDeviceToHost, st));
-                        HIP_CHECK(hipStreamSynchronize(st));
-                        keep = o->callback(i, t, cb_buf.data(), no, o->callback_user);
+                    const int kind = o->callback_kind;
+                    if (kind == SDE_CB_PROGRESS && i % freq == 0) {
+                        if (!o->callback(i, t, nullptr, 0, o->callback_user)) { stopped = true; break; }  // :319-321, still decodes
+                    } else if ((kind == SDE_CB_LATENTS && i % freq == 0) ||
+                               ((kind == SDE_CB_DECODED || kind == SDE_CB_APPROXIMATE) && i != 0 && i % freq == 0)) {
+                        PreviewLane& L = preview_lane(e);
+                        HIP_CHECK(hipEventRecord(L.ready, st));
+                        HIP_CHECK(hipStreamWaitEvent(L.stream, L.ready, 0));
+                        size_t no = per;
+                        const float* src = d_lat;
+                        if (kind == SDE_CB_DECODED) {
+                            const int up = e->vae.upscale();
+                            no = (size_t)B * h * up * w * up * e->vae.out_channels;
+                            L.images.ensure(no * 4);
+                            decode_on_lane(e, L, d_lat, B, h, w, L.images.as<float>());
+                            src = L.images.as<float>();
+                        } else if (kind == SDE_CB_APPROXIMATE) {
+                            no = (size_t)B * h * w * 3;
+                            L.images.ensure(no * 4);
+                            launch_approx_decode(L.ctx, d_lat, L.images.as<float>(), B, h, w);
+                            src = L.images.as<float>();
+                        }
+                        L.host.ensure(no * 4);
+                        HIP_CHECK(hipMemcpyAsync(L.host.p, src, no * 4, hipMemcpyDeviceToHost, L.stream));
+                        HIP_CHECK(hipEventRecord(L.done, L.stream));
+                        pending_cb = true; pending_i = i; pending_t = t; pending_n = no;
                     }
-                    if (!keep) break;  // the reference breaks out of the loop and still decodes (:319-326)
                 }
             }
         }
@@ -725,6 +864,11 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             if (!o->buffers_on_device && nb > 0)
                 HIP_CHECK(hipMemcpyAsync(images_out + (size_t)b0 * img, e->images.p, no * 4, hipMemcpyDeviceToHost, st));
         } else HIP_CHECK(hipEventRecord(ev2, st));
+        if (pending_cb && !stopped) {   // the last step's payload (i == nt - 1 always fires, :307), delivered while the final decode runs
+            HIP_CHECK(hipEventSynchronize(e->preview->done));
+            pending_cb = false;
+            (void)o->callback(pending_i, pending_t, e->preview->host.as<float>(), pending_n, o->callback_user);
+        }
         HIP_CHECK(hipStreamSynchronize(st));
         if (stats) {
             float a = 0, b = 0;
@@ -770,7 +914,7 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
     return guarded([&] {
         SDE_REQUIRE(e && x && w && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
         SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
-        std::lock_guard<std::mutex> lk(e->mu);
+        EngineLock lk(e);
         engine_activate(e);
         LaunchCtx ctx = e->ctx; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3;   // 0 fast, 1 plain, 2 / 3 force the 256x320 / 256x160 kernel
         const int taps = ksize * ksize;
@@ -806,7 +950,7 @@ sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const fl
 {
     return guarded([&] {
         SDE_REQUIRE(e && q && k && v && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
-        std::lock_guard<std::mutex> lk(e->mu);
+        EngineLock lk(e);
         engine_activate(e);
         LaunchCtx ctx = e->ctx; ctx.force_naive = naive != 0;
         const int C = heads * d;

@@ -280,7 +280,7 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     p.M = a.M; p.N = a.N; p.K = a.K; p.taps = a.taps; p.stride = a.stride; p.ups = a.ups;
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
     p.Hs = a.ups ? (a.Hi + 1) / 2 : a.Hi; p.Ws = a.ups ? (a.Wi + 1) / 2 : a.Wi;   // ups: virtual (Hi x Wi) = nearest-2x of (Hs x Ws), cropped when odd
-    p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
+    p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.Rlo = a.Rlo; p.Dlo = a.Dlo; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
     p.epi = a.epi; p.gelu_tanh = a.gelu_tanh; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
     p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr; p.stamps = nullptr;
     // fabric reads ~ A + 8*W with column tiles fastest, 8*A + W with row tiles fastest (8 XCDs, each with its own L2)
@@ -365,12 +365,14 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     SDE_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.A0 && a.W, SDE_ERR_INVALID_ARGUMENT, "launch_gemm: empty problem");
     SDE_REQUIRE(a.K == a.taps * (a.C0 + a.C1), SDE_ERR_INVALID_ARGUMENT, "launch_gemm: K != taps*(C0+C1)");
     SDE_REQUIRE(a.N <= a.Npad, SDE_ERR_INVALID_ARGUMENT, "launch_gemm: N > Npad");
+    SDE_REQUIRE((!a.Rlo && !a.Dlo) || a.epi == EPI_STD, SDE_ERR_INVALID_ARGUMENT, "launch_gemm: split-fp16 residual / result needs EPI_STD");
+    SDE_REQUIRE(!a.Rlo || a.R, SDE_ERR_INVALID_ARGUMENT, "launch_gemm: Rlo without R");
     if (a.taps == 9)
         SDE_REQUIRE(a.M % (a.Ho * a.Wo) == 0 && a.Ho > 0 && a.Wo > 0 && a.Hi > 0 && a.Wi > 0, SDE_ERR_INVALID_ARGUMENT,
                     "launch_gemm: conv geometry");
     GemmDev p = to_dev(ctx, a);
     const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
-    const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (a.R ? 2 : 1)) * 2.0 * a.batch;
+    const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (1 + (a.R ? 1 : 0) + (a.Rlo ? 1 : 0) + (a.Dlo ? 1 : 0))) * 2.0 * a.batch;
     static const int big_env = getenv("SDE_BIG") ? atoi(getenv("SDE_BIG")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
     if (!ctx.force_naive && big_env && !ctx.force_mid && gemm_big_supported(a)) {
         // 8-wave 256x320 tiles, one block per CU: worth it once the grid (with split-K on long K) covers most of the chip

@@ -15,7 +15,7 @@ struct GemmDev {
     int C0, C1, lda0, lda1;
     int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws;
     const half_t* W; int Npad;
-    const float* bias; const half_t* R; int ldr;
+    const float* bias; const half_t* R; const half_t* Rlo; half_t* Dlo; int ldr;
     half_t* D; float* Df; int ldd; int epi; int gelu_tanh; float alpha;
     long long sA, sW, sD, sR;
     const half_t* zeros;
@@ -67,14 +67,26 @@ __device__ __forceinline__ void epilogue4(const GemmDev& p, int m, int n, floatx
                 half4 rr = *(const half4*)(p.R + zR + (long long)m * p.ldr + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] += (float)rr[r];
+                if (p.Rlo) {
+                    half4 rl = *(const half4*)(p.Rlo + zR + (long long)m * p.ldr + n);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += (float)rl[r];
+                }
             }
             half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
             *(half4*)(p.D + zD + (long long)m * p.ldd + n) = h;
+            if (p.Dlo) {
+                half4 l = {(half_t)(o[0] - (float)h[0]), (half_t)(o[1] - (float)h[1]), (half_t)(o[2] - (float)h[2]), (half_t)(o[3] - (float)h[3])};
+                *(half4*)(p.Dlo + zD + (long long)m * p.ldd + n) = l;
+            }
         } else {
             for (int r = 0; r < 4 && n + r < p.N; ++r) {
                 float x = o[r];
                 if (p.R) x += (float)p.R[zR + (long long)m * p.ldr + n + r];
-                p.D[zD + (long long)m * p.ldd + n + r] = (half_t)x;
+                if (p.R && p.Rlo) x += (float)p.Rlo[zR + (long long)m * p.ldr + n + r];
+                const half_t h = (half_t)x;
+                p.D[zD + (long long)m * p.ldd + n + r] = h;
+                if (p.Dlo) p.Dlo[zD + (long long)m * p.ldd + n + r] = (half_t)(x - (float)h);
             }
         }
     } else if (p.epi == EPI_GEGLU || p.epi == EPI_GEGLU_PAIR) {

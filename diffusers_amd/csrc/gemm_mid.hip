@@ -74,11 +74,13 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
         for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
     }
     const half_t* R = p.R ? p.R + zR : nullptr;
+    const half_t* Rlo = (p.R && p.Rlo) ? p.Rlo + zR : nullptr;   // split-fp16 residual / result (kernels.h)
     half_t* D = p.D + zD;
+    half_t* Dlo = p.Dlo ? p.Dlo + zD : nullptr;
     const bool rvec_ok = R && (p.ldr & 7) == 0;
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
-        half8 rr[NI];
+        half8 rr[NI], rl[NI];
         if (R) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -86,6 +88,10 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
                 const int m = min(m0 + wr * 64 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
                 if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
                 else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
+                if (Rlo) {
+                    if (rvec_ok) rl[i] = *(const half8*)(Rlo + (long long)m * p.ldr + n);
+                    else for (int e = 0; e < 8; ++e) rl[i][e] = Rlo[(long long)m * p.ldr + n + e];
+                }
             }
         }
 #pragma unroll
@@ -107,12 +113,22 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
             const int m = m0 + wr * 64 + ms * 32 + row, n = n0 + wc * WN + ch * 8;
             const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
             const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            half8 v;
+            half8 v, vl;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (half_t)(R ? f[e] + (float)rr[i][e] : f[e]);
+            for (int e = 0; e < 8; ++e) {
+                float x = R ? f[e] + (float)rr[i][e] : f[e];
+                if (Rlo) x += (float)rl[i][e];
+                v[e] = (half_t)x;
+                vl[e] = (half_t)(x - (float)v[e]);
+            }
             if (m < p.M && n < p.N) {
-                if (vec_ok && n + 8 <= p.N) *(half8*)(D + (long long)m * p.ldd + n) = v;
-                else for (int e = 0; e < 8 && n + e < p.N; ++e) D[(long long)m * p.ldd + n + e] = v[e];
+                if (vec_ok && n + 8 <= p.N) {
+                    *(half8*)(D + (long long)m * p.ldd + n) = v;
+                    if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;
+                } else for (int e = 0; e < 8 && n + e < p.N; ++e) {
+                    D[(long long)m * p.ldd + n + e] = v[e];
+                    if (Dlo) Dlo[(long long)m * p.ldd + n + e] = vl[e];
+                }
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -59,6 +59,11 @@ struct GemmArgs {
     int Npad = 0;
     const float* bias = nullptr; // [N] or null
     const half_t* R = nullptr;   // residual [M][ldr] or null
+    // Split-fp16 tensors (EPI_STD only): a tensor that is never an MFMA operand is kept as hi + lo, hi = half(x), lo = half(x - hi)
+    // (~22 significant bits, same layout and stride as its hi part).  Rlo: low part of the residual; Dlo: where to store the
+    // low part of the result.  Consumers that need an MFMA operand read hi alone.  DESIGN.md section 2.
+    const half_t* Rlo = nullptr;
+    half_t* Dlo = nullptr;
     int ldr = 0;
     half_t* D = nullptr;
     float* Df = nullptr;
@@ -91,6 +96,7 @@ bool attention_mfma_supported(const AttnArgs& a);
 // GroupNorm over NHWC (optionally a channel concat of two sources), fused affine (+SiLU).
 struct GroupNormArgs {
     const half_t* X0 = nullptr; const half_t* X1 = nullptr;
+    const half_t* X0lo = nullptr; const half_t* X1lo = nullptr;   // low parts of split-fp16 inputs (or null): added before normalising
     int C0 = 0, C1 = 0;
     int NB = 0, HW = 0, groups = 32;
     float eps = 1e-5f;
@@ -104,6 +110,11 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a);
 
 void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows, int C, const float* gamma,
                       const float* beta, float eps);
+// y = LayerNorm(S32 + A + B) with the sum formed and kept in fp32 (any of the three may be null, not all); S32_out (optional) receives the sum
+void launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows, int C,
+                          const float* gamma, const float* beta, float eps);
+// Y = half(S32 + A + B), n elements (n % 8 == 0)
+void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, int64_t n);
 // in-place softmax over the last dim of a [rows][cols] fp16 matrix (fp32 math)
 void launch_softmax_rows(const LaunchCtx& ctx, half_t* X, int64_t rows, int cols, int pitch);   // in place; columns [cols, pitch) become 0
 
@@ -136,7 +147,7 @@ struct RepackArgs {
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& a);
 
 // ------------------------------------------------------------------------------------------ fused CFG + scheduler step
-enum StepKind { STEP_EULER = 0, STEP_EULER_A = 1, STEP_DPM1 = 2, STEP_DPM2M = 3, STEP_DDIM = 4, STEP_DDPM = 5, STEP_LMS = 6 };
+enum StepKind { STEP_EULER = 0, STEP_EULER_A = 1, STEP_DPM1 = 2, STEP_DPM2M = 3, STEP_DDIM = 4, STEP_DDPM = 5, STEP_LMS = 6, STEP_DPM3M = 7 };
 struct StepArgs {
     int kind = 0;
     int pred = 0;            // sde_prediction_type
@@ -147,9 +158,10 @@ struct StepArgs {
     const float* model_out = nullptr;       // f32 NCHW [N,4,h,w]
     float* latents = nullptr;               // f32 NCHW [B,4,h,w], updated in place
     const float* noise = nullptr;           // f32 [B,4,h,w] or null
-    float c[8] = {0};                       // scheduler coefficients (meaning per kind, scheduler.cpp)
+    float c[12] = {0};                      // scheduler coefficients (meaning per kind, scheduler.cpp)
     int clip = 0;
-    float* hist[4] = {nullptr, nullptr, nullptr, nullptr};  // history buffers (DPM 2M: x0; LMS: derivatives), f32 [B,4,h,w]
+    int dpm_algo = 0;                       // sde_dpm_algorithm: how DPM-Solver converts the model output (dpm_solver_multistep.rs:211-246)
+    float* hist[4] = {nullptr, nullptr, nullptr, nullptr};  // history buffers (DPM multistep: converted outputs; LMS: derivatives), f32 [B,4,h,w]
     int nhist = 0;
     float lms_c[4] = {0};
     float next_input_scale = 1.0f;          // next step's scale_model_input factor (1/sqrt(sigma^2+1) or 1)

@@ -384,6 +384,127 @@ void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows
     HIP_CHECK(hipGetLastError());
 }
 
+
+// LayerNorm over a SUM kept in fp32: x = S32 + A + B (each optional but one), y = LN(x) in fp16, optionally x written back as
+// fp32.  This is how the transformer blocks carry their residual stream (model.cpp): the branch outputs (attention, feed-forward)
+// stay fp16 GEMM outputs, the running sum is never rounded to fp16 between sub-layers (the rounding of the
+// residual stream at every residual add was the largest single contribution to the engine-vs-fp32 error).
+template <int NOCT, int LN_ROWS>
+__global__ __launch_bounds__(256) void layernorm_sum_kernel(const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows,
+                                                            int C, const float* gamma, const float* beta, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LN_ROWS;
+    if (row0 >= rows) return;
+    const int CX = C >> 3;
+    float v[LN_ROWS][NOCT][8];
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        const long long off = (long long)min(row0 + r, rows - 1) * C;
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) {
+            const int cx = lane + o * 64;
+            if (cx < CX) {
+                float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+                if (S32) { s0 = *(const float4*)(S32 + off + cx * 8); s1 = *(const float4*)(S32 + off + cx * 8 + 4); }
+                v[r][o][0] = s0.x; v[r][o][1] = s0.y; v[r][o][2] = s0.z; v[r][o][3] = s0.w;
+                v[r][o][4] = s1.x; v[r][o][5] = s1.y; v[r][o][6] = s1.z; v[r][o][7] = s1.w;
+                if (A) {
+                    half8 a = *(const half8*)(A + off + cx * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[r][o][j] += (float)a[j];
+                }
+                if (B) {
+                    half8 b = *(const half8*)(B + off + cx * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[r][o][j] += (float)b[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < LN_ROWS; ++r) {
+        float sum = 0.f;
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) {
+            if (lane + o * 64 < CX) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sum += v[r][o][j];
+            }
+        }
+        const float mean = wave_sum(sum) / (float)C;
+        float sq = 0.f;
+#pragma unroll
+        for (int o = 0; o < NOCT; ++o) {
+            if (lane + o * 64 < CX) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float dlt = v[r][o][j] - mean; sq += dlt * dlt; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+        if (row0 + r < rows) {
+            const long long off = (long long)(row0 + r) * C;
+#pragma unroll
+            for (int o = 0; o < NOCT; ++o) {
+                const int cx = lane + o * 64;
+                if (cx < CX) {
+                    if (S32_out) {
+                        *(float4*)(S32_out + off + cx * 8) = make_float4(v[r][o][0], v[r][o][1], v[r][o][2], v[r][o][3]);
+                        *(float4*)(S32_out + off + cx * 8 + 4) = make_float4(v[r][o][4], v[r][o][5], v[r][o][6], v[r][o][7]);
+                    }
+                    half8 out;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        out[j] = (half_t)((v[r][o][j] - mean) * rstd * gamma[cx * 8 + j] + beta[cx * 8 + j]);
+                    *(half8*)(Y + off + cx * 8) = out;
+                }
+            }
+        }
+    }
+}
+
+void launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows, int C,
+                          const float* gamma, const float* beta, float eps)
+{
+    SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
+    SDE_REQUIRE(S32 || A || B, SDE_ERR_INVALID_ARGUMENT, "layernorm_sum: no input");
+    ProfScope ps(ctx, "layernorm_sum", 0, (double)rows * C * ((S32 ? 4.0 : 0.0) + (A ? 2.0 : 0.0) + (B ? 2.0 : 0.0) + (S32_out ? 4.0 : 0.0) + 2.0));
+    const int noct = cdiv(C / 8, 64);
+    const dim3 block(256);
+#define LN_LAUNCH(O, R) hipLaunchKernelGGL((layernorm_sum_kernel<O, R>), dim3(cdiv(rows, 4 * R)), block, 0, ctx.stream, S32, A, B, S32_out, Y, rows, C, gamma, beta, eps)
+    if (rows >= 32768 && noct <= 2) {
+        if (noct == 1) LN_LAUNCH(1, 4); else LN_LAUNCH(2, 4);
+    } else if (rows >= 8192) {
+        if (noct == 1) LN_LAUNCH(1, 2); else if (noct == 2) LN_LAUNCH(2, 2); else if (noct == 3) LN_LAUNCH(3, 2); else LN_LAUNCH(4, 2);
+    } else {
+        if (noct == 1) LN_LAUNCH(1, 1); else if (noct == 2) LN_LAUNCH(2, 1); else if (noct == 3) LN_LAUNCH(3, 1); else LN_LAUNCH(4, 1);
+    }
+#undef LN_LAUNCH
+    HIP_CHECK(hipGetLastError());
+}
+
+// y = half(S32 + A + B): the one rounding of a transformer block's residual stream, before proj_out reads it as an MFMA operand
+__global__ void sum_round_kernel(const float* S32, const half_t* A, const half_t* B, half_t* Y, long long n8)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const float4 s0 = *(const float4*)(S32 + i * 8), s1 = *(const float4*)(S32 + i * 8 + 4);
+        const half8 a = *(const half8*)(A + i * 8), b = *(const half8*)(B + i * 8);
+        const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)(s[j] + (float)a[j] + (float)b[j]);
+        *(half8*)(Y + i * 8) = o;
+    }
+}
+void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, int64_t n)
+{
+    SDE_REQUIRE(n % 8 == 0 && S32 && A && B, SDE_ERR_INVALID_ARGUMENT, "sum_round: bad arguments");
+    ProfScope ps(ctx, "residual_sum_round", 0, 10.0 * n);
+    hipLaunchKernelGGL(sum_round_kernel, dim3((unsigned)std::min<long long>(cdiv64(n / 8, 256), 8192)), dim3(256), 0, ctx.stream, S32, A, B, Y,
+                       (long long)(n / 8));
+    HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ row softmax (VAE attention)
 __global__ void softmax_rows_kernel(half_t* X, long long rows, int cols, int pitch)
 {

@@ -2,6 +2,7 @@
 // reference's Rust f32 expressions are.
 #include "scheduler.h"
 
+#include <algorithm>
 #include <cmath>
 
 namespace {
@@ -51,7 +52,7 @@ struct Interp {
     }
     float eval(float v)
     {
-        if (v < x.front() || v > x.back()) return NAN;
+        if (x.size() < 2 || v < x.front() || v > x.back()) return NAN;
         if (v < x[cache]) cache = bsearch(x, v, 0, cache);
         else if (v >= x[cache + 1]) cache = bsearch(x, v, cache, x.size() - 1);
         size_t i = cache;
@@ -78,6 +79,11 @@ void sde_scheduler::init(int k, const sde_sched_cfg& c)
     SDE_REQUIRE(is_normal(c.beta_start) && is_normal(c.beta_end), SDE_ERR_INVALID_ARGUMENT,
                 "beta_start and beta_end must be normal (not zero, infinite, NaN, or subnormal)");
     SDE_REQUIRE(c.beta_start < c.beta_end, SDE_ERR_INVALID_ARGUMENT, "beta_start must be < beta_end");
+    if (k == SDE_SCHED_DPMPP) {
+        SDE_REQUIRE(c.solver_order >= 1 && c.solver_order <= 3, SDE_ERR_INVALID_ARGUMENT, "solver_order must be 1, 2 or 3");
+        SDE_REQUIRE(c.algorithm_type == SDE_DPM_SOLVER_PP || c.algorithm_type == SDE_DPM_SOLVER, SDE_ERR_INVALID_ARGUMENT, "unknown algorithm_type");
+        SDE_REQUIRE(c.solver_type == SDE_DPM_MIDPOINT || c.solver_type == SDE_DPM_HEUN, SDE_ERR_INVALID_ARGUMENT, "unknown solver_type");
+    }
     // betas (euler_discrete.rs:74-84)
     if (c.beta_schedule == SDE_BETA_LINEAR) betas = nd_linspace(c.beta_start, c.beta_end, T);
     else if (c.beta_schedule == SDE_BETA_SCALED_LINEAR) {
@@ -129,7 +135,9 @@ void sde_scheduler::set_timesteps(int n)
     SDE_REQUIRE(n >= 1, SDE_ERR_INVALID_ARGUMENT, "num_inference_steps must be >= 1");
     num_inference_steps = n;
     if (scales_input()) {
-        // euler_discrete.rs:152-173
+        // euler_discrete.rs:152-173.  The interpolator indexes x[i + 1]: with a one-entry training table the reference panics on the
+        // bounds check (util/interpolation.rs:98-99); here that is an error status
+        SDE_REQUIRE(T >= 2, SDE_ERR_SCHEDULER, "sigma interpolation needs num_train_timesteps >= 2");
         timesteps = nd_linspace((float)T - 1.0f, 0.0f, n);
         std::vector<float> sg((size_t)T);
         for (int i = 0; i < T; ++i) { float ac = alphas_cumprod[(size_t)i]; float r = (1.0f - ac) / ac; sg[(size_t)i] = std::sqrt(r); }
@@ -229,22 +237,55 @@ void sde_scheduler::plan(float t, StepPlan& p)
         SDE_REQUIRE(i >= 0, SDE_ERR_SCHEDULER, "timestep out of this schedulers bounds: " + std::to_string(t));
         int ts = (int)t;
         int prev = (i == n - 1) ? 0 : (int)timesteps[(size_t)i + 1];
-        bool lower_final = (i == n - 1) && cfg.lower_order_final && n < 15;
-        // REFERENCE_QUIRK: lower_order_nums is never incremented there => always first order
-        bool first = cfg.solver_order == 1 || lower_order_nums < 1 || lower_final;
+        const bool lower_final = (i == n - 1) && cfg.lower_order_final && n < 15;
+        const bool lower_second = (i == n - 2) && cfg.lower_order_final && n < 15;
+        const bool dpmpp = cfg.algorithm_type == SDE_DPM_SOLVER_PP;
         float lam_t = lambda_t[(size_t)prev], lam_s = lambda_t[(size_t)ts];
         float h = lam_t - lam_s;
-        float em = std::exp(-h) - 1.0f;
+        // REFERENCE_QUIRK: lower_order_nums is never incremented there => always first order (:369)
+        bool first = cfg.solver_order == 1 || lower_order_nums < 1 || lower_final;
+        // "fixed" mode only: the last timestep of linspace(T-1, 0, n) is 0 and its prev_timestep is 0 as well, so h == 0 and the
+        // multistep formulas divide by it (r0 = h0 / 0; Heun: 0 / 0).  The first-order update is the identity there.
+        if (!cfg.reference_quirks && h == 0.0f) first = true;
+        p.dpm_algo = cfg.algorithm_type;
         p.c[0] = alpha_t[(size_t)ts]; p.c[1] = sigma_t[(size_t)ts];
-        p.c[2] = sigma_t[(size_t)prev] / sigma_t[(size_t)ts];
-        p.c[3] = alpha_t[(size_t)prev] * em;
-        p.nhist = cfg.reference_quirks ? 0 : 2;
+        // first-order coefficients (:248-257); the multistep updates reuse them for the sample and d0 terms
+        float ex;   // D++: exp(-h) - 1 ; DPMSolver: exp(h) - 1
+        if (dpmpp) {
+            ex = std::exp(-h) - 1.0f;
+            p.c[2] = sigma_t[(size_t)prev] / sigma_t[(size_t)ts];
+            p.c[3] = alpha_t[(size_t)prev] * ex;
+        } else {
+            ex = std::exp(h) - 1.0f;
+            p.c[2] = alpha_t[(size_t)prev] / alpha_t[(size_t)ts];
+            p.c[3] = sigma_t[(size_t)prev] * ex;
+        }
+        const float outer = dpmpp ? alpha_t[(size_t)prev] : sigma_t[(size_t)prev];
+        p.nhist = cfg.reference_quirks ? 0 : std::max(2, std::min(cfg.solver_order, 3));
         if (first) p.kind = STEP_DPM1;
-        else {  // :259-278 (midpoint)
+        else if (cfg.solver_order == 2 || lower_order_nums < 2 || lower_second) {  // :371-373, :259-285
             int s1 = (int)timesteps[(size_t)i - 1];
             float h0 = lam_s - lambda_t[(size_t)s1];
             float r0 = h0 / h;
-            p.kind = STEP_DPM2M; p.c[4] = 1.0f / r0; p.c[5] = 0.5f * p.c[3];
+            p.kind = STEP_DPM2M; p.c[4] = 1.0f / r0;
+            if (cfg.solver_type == SDE_DPM_MIDPOINT) p.c[5] = 0.5f * p.c[3];                       // :278,282
+            else if (dpmpp) { float q = ex / h + 1.0f; p.c[5] = -(outer * q); }                    // :279 (added there: passed negated)
+            else { float q = ex / h - 1.0f; p.c[5] = outer * q; }                                  // :283
+        } else {                                                                                   // :374-376, :288-326
+            int s1 = (int)timesteps[(size_t)i - 1], s2 = (int)timesteps[(size_t)i - 2];
+            float lam_s1 = lambda_t[(size_t)s1], lam_s2 = lambda_t[(size_t)s2];
+            float h0 = lam_s - lam_s1, h1 = lam_s1 - lam_s2;
+            float r0 = h0 / h, r1 = h1 / h;
+            p.kind = STEP_DPM3M;
+            p.c[4] = 1.0f / r0; p.c[6] = 1.0f / r1; p.c[7] = r0 / (r0 + r1); p.c[8] = 1.0f / (r0 + r1);
+            float h2 = h * h;
+            if (dpmpp) {
+                float q1 = ex / h + 1.0f; p.c[5] = -(outer * q1);                                  // :316 (added there)
+                float q2 = (ex + h) / h2 - 0.5f; p.c[9] = outer * q2;                              // :317
+            } else {
+                float q1 = ex / h - 1.0f; p.c[5] = outer * q1;                                     // :322
+                float q2 = (ex - h) / h2 - 0.5f; p.c[9] = outer * q2;                              // :323
+            }
         }
         return;
     }
@@ -300,6 +341,14 @@ void sde_scheduler::advance(const StepPlan& p)
         lms_hist = std::min(lms_hist + 1, 4);
     }
     (void)p;
+}
+
+void sde_scheduler::rotate_history(const StepPlan& p, float** hist) const
+{
+    // DPM multistep: the kernel wrote the converted output into hist[nhist-1]; it becomes hist[0] (m1 of the next step)
+    if (kind == SDE_SCHED_DPMPP && p.nhist > 1) std::rotate(hist, hist + p.nhist - 1, hist + p.nhist);
+    // LMS: the kernel wrote the new derivative into hist[0] and read hist[1..3]; shift so that hist[0] is the free slot again
+    if (kind == SDE_SCHED_LMS) std::rotate(hist, hist + 3, hist + 4);
 }
 
 void sde_scheduler::add_noise_coeffs(float t, float& a, float& b)

@@ -9,10 +9,11 @@
 struct StepPlan {
     int kind = STEP_EULER;      // StepKind
     int pred = SDE_PRED_EPSILON;
-    float c[8] = {0};
+    float c[12] = {0};
     int clip = 0;
+    int dpm_algo = 0;           // sde_dpm_algorithm
     bool needs_noise = false;   // noise tensor is consumed by this step
-    int nhist = 0;              // DPM 2M: 2 buffers ; LMS: terms in the sum
+    int nhist = 0;              // DPM multistep: buffers in rotation (solver_order) ; LMS: terms in the sum
     float lms_c[4] = {0};
 };
 
@@ -43,6 +44,9 @@ struct sde_scheduler {
     bool is_int_timestep() const { return kind == SDE_SCHED_DPMPP || kind == SDE_SCHED_DDIM; }
     void plan(float t, StepPlan& p);                // coefficients for the step at timestep t (no state change)
     void advance(const StepPlan& p);                // state change the reference's `step` makes
+    // after a step's kernel: bring the history buffers into the order the next step's kernel expects (the slot the
+    // kernel just wrote becomes hist[0])
+    void rotate_history(const StepPlan& p, float** hist) const;
     void add_noise_coeffs(float t, float& a, float& b);  // out = a*x0 + b*noise
     ~sde_scheduler();
 };

@@ -193,6 +193,9 @@ class StableDiffusionTxt2ImgOptions:
         self.ensd = ensd
         return self
 
+    # Callbacks run on the calling thread inside the engine's locked call (as the reference runs them inside `run`): they must not
+    # call back into the same pipeline (unet / decode_latents / run ...); such a call raises SdeError("re-entered") instead of
+    # deadlocking.  An exception raised by a callback stops the loop and is re-raised by run().
     def callback_progress(self, frequency: int, cb: Callable[[int, float], bool]):
         self.callback_kind, self.callback_frequency, self.callback = CB_PROGRESS, frequency, lambda i, t, p: cb(i, t)
         return self
@@ -232,6 +235,7 @@ class StableDiffusionTxt2ImgOptions:
             o.S, o.D = device_ptrs["S"], device_ptrs["D"]
             o.init_latents = device_ptrs.get("init_latents")
             o.step_noise = device_ptrs.get("step_noise")
+            o.step_noise_rows = device_ptrs.get("step_noise_rows", 0)
             images_ptr = device_ptrs.get("images")
             images = None
         else:
@@ -250,8 +254,11 @@ class StableDiffusionTxt2ImgOptions:
                 o.init_latents = il.ctypes.data
             if self.step_noise is not None:
                 sn = np.ascontiguousarray(self.step_noise, np.float32)
+                if sn.ndim < 2 or sn[0].size != B * 4 * h * w:
+                    raise ValueError(f"step_noise must be [n_timesteps,{B},4,{h},{w}], got {sn.shape}")
                 keep.append(sn)
                 o.step_noise = sn.ctypes.data
+                o.step_noise_rows = sn.shape[0]     # the engine rejects a run whose scheduler yields more timesteps than rows
             mi = session.info()
             up = 1 << (mi.vae_n_levels - 1) if mi.vae_loaded else 8   # 8 for SD VAEs => [B,H,W,3]
             images = None if skip_decode else np.empty((B, h * up, w * up, 3), np.float32)
@@ -264,7 +271,16 @@ class StableDiffusionTxt2ImgOptions:
             cb_mi = session.info()
             cb_up = 1 << (cb_mi.vae_n_levels - 1) if cb_mi.vae_loaded else 8
 
+            cb_errors = []
+
             def tramp(step, t, payload, n, _user):
+                try:
+                    return tramp_body(step, t, payload, n)
+                except BaseException as exc:   # ctypes would swallow it and read "stop": keep it and re-raise after the run
+                    cb_errors.append(exc)
+                    return 0
+
+            def tramp_body(step, t, payload, n):
                 arr = None
                 if payload and n:
                     arr = np.ctypeslib.as_array(payload, shape=(n,)).copy()
@@ -279,9 +295,15 @@ class StableDiffusionTxt2ImgOptions:
             cfn = _lib.CALLBACK(tramp)
             keep.append(cfn)
             o.callback, o.callback_kind, o.callback_frequency = cfn, kind, self.callback_frequency
+        else:
+            cb_errors = []
         if trace and device_ptrs is None:
-            # upper bound on the number of UNet calls: timesteps are set inside run(); size generously
-            nmax = self.steps + 2
+            # one row per TIMESTEP, which is the scheduler's count and not `steps` (DDIM: steps - 1; DDPM: ceil(T / (T // steps)),
+            # e.g. 167 rows for steps = 150): run() calls set_timesteps(steps) itself (impl_txt2img.rs:264), doing it here first
+            # is idempotent and tells us the size
+            scheduler.set_timesteps(self.steps)
+            nmax = len(scheduler.timesteps())
+            o.trace_rows = nmax
             res.noise_pred = np.zeros((nmax, B, 4, h, w), np.float32)
             res.latents = np.zeros((nmax, B, 4, h, w), np.float32)
             res.final_latents = np.zeros((B, 4, h, w), np.float32)
@@ -308,6 +330,8 @@ class StableDiffusionTxt2ImgOptions:
             if cfg_pair is not None and pair_errors:
                 raise pair_errors[0] from err
             raise
+        if cb_errors:
+            raise cb_errors[0]
         res.unet_calls, res.total_ms, res.unet_ms, res.vae_ms = st.unet_calls, st.total_ms, st.unet_ms, st.vae_ms
         res.host_enqueue_ms = st.host_enqueue_ms
         if trace and res.noise_pred is not None:

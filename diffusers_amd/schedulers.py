@@ -18,6 +18,8 @@ EULER, EULER_A, DPMPP, DDIM, DDPM, LMS = range(6)
 BETA = {"linear": 0, "scaled_linear": 1, "squaredcos_cap_v2": 2}
 PRED = {"epsilon": 0, "sample": 1, "v_prediction": 2}
 VARIANCE = {"fixed_small": 0, "fixed_small_log": 1, "fixed_large": 2, "fixed_large_log": 3, "learned": 4}
+DPM_ALGORITHM = {"dpmsolver++": 0, "dpmsolver": 1}   # DPMSolverAlgorithmType (dpm_solver_multistep.rs:30-36)
+DPM_SOLVER = {"midpoint": 0, "heun": 1}              # DPMSolverType (:43-49)
 
 
 def _f32(a) -> np.ndarray:
@@ -46,6 +48,10 @@ class DiffusionScheduler:
         for k, v in config.items():
             if k == "variance_type":
                 v = VARIANCE[v]
+            elif k == "algorithm_type" and isinstance(v, str):
+                v = DPM_ALGORITHM[v]
+            elif k == "solver_type" and isinstance(v, str):
+                v = DPM_SOLVER[v]
             if not hasattr(cfg, k):
                 raise TypeError(f"unknown scheduler option {k}")
             setattr(cfg, k, int(v))
@@ -105,8 +111,8 @@ class DiffusionScheduler:
         return out
 
     def step(self, model_output, timestep, sample, noise=None) -> np.ndarray:
-        """``rng`` of the reference becomes an explicit N(0,1) ``noise`` tensor (the engine's RNG stream is
-        not rand::StdRng-compatible; parity runs inject the draws)."""
+        """``rng`` of the reference becomes an explicit N(0,1) ``noise`` tensor: draw it with ``sde_rng_standard_normal``
+        (the restated StdRng / StandardNormal stream of the reference) or inject any other draws."""
         mo, s = _f32(model_output), _f32(sample)
         nz = _f32(noise) if noise is not None else None
         out = np.empty_like(s)

@@ -119,7 +119,12 @@ typedef struct sde_sched_cfg {
     int clip_sample, set_alpha_to_one, steps_offset;
     /* DDPM */
     int variance_type;         /* 0 fixed_small, 1 fixed_small_log, 2 fixed_large, 3 fixed_large_log, 4 learned */
+    /* DPM-Solver, continued (dpm_solver_multistep.rs:30-49,71-74) */
+    int algorithm_type;        /* sde_dpm_algorithm: 0 DPMSolverPlusPlus (default), 1 DPMSolver (:232-244,255,282-283,319-324) */
+    int solver_type;           /* sde_dpm_solver_type: 0 Midpoint (default), 1 Heun (:279,283); second-order update only */
 } sde_sched_cfg;
+typedef enum sde_dpm_algorithm { SDE_DPM_SOLVER_PP = 0, SDE_DPM_SOLVER = 1 } sde_dpm_algorithm;
+typedef enum sde_dpm_solver_type { SDE_DPM_MIDPOINT = 0, SDE_DPM_HEUN = 1 } sde_dpm_solver_type;
 
 /* `stable_diffusion_v1_optimized_default()` of the given kind (euler_discrete.rs:261,
  * dpm_solver_multistep.rs:404-419, ddim.rs:275-286, ddpm.rs:269). */
@@ -151,6 +156,10 @@ typedef enum sde_callback_kind {  /* StableDiffusionCallback, pipelines/stable_d
 /* step index, timestep, payload (NULL / latents [B,4,h,w] / images [B,H,W,3] / images [B,h,w,3]),
  * payload element count, user pointer.  Return 0 to stop the loop (reference: `false` -> break). */
 typedef int (*sde_callback_fn)(int step, float timestep, const float* payload, size_t payload_len, void* user);
+/* Callbacks (and the exchange hook below) run on the calling thread while the engine's lock is held, as the reference runs
+ * them inside `run(&self, ..)`: a callback must NOT call back into the same engine (sde_unet_forward, sde_vae_decode,
+ * sde_approximate_decode, sde_txt2img_run ...) -- such a call is refused with SDE_ERR_INVALID_ARGUMENT ("re-entered")
+ * instead of deadlocking.  Use the Decoded / ApproximateDecoded kinds for previews, or a second engine. */
 
 /* CFG-pair split (BASELINE config 3): two engines on two GPUs each run ONE half of the classifier-free-guidance
  * batch (impl_txt2img.rs:273-301 computes both in one session.run) and swap the halves once per step.  The engine calls this
@@ -184,6 +193,13 @@ typedef struct sde_txt2img_opts {
      * Each engine decodes its share of the batch: rows [0, ceil(B/2)) of images_out on the unconditional engine, rows
      * [ceil(B/2), B) on the text engine; the other rows are left untouched. */
     int cfg_half; sde_exchange_fn exchange; void* exchange_user;
+    /* Row capacities of the optional per-timestep buffers.  The number of timesteps is the scheduler's, not `steps`
+     * (DDIM: steps - 1, ddim.rs:184; DDPM: ceil(T / (T / steps)), ddpm.rs:181 -- e.g. 167 for steps = 150), so a caller
+     * sizes them from sde_scheduler_num_timesteps after sde_scheduler_set_timesteps(steps) and states the size here:
+     * the run is rejected (SDE_ERR_INVALID_ARGUMENT) before anything is written when a buffer is too short.
+     * 0 = not stated (then `steps` rows are assumed and a scheduler that yields more timesteps is rejected). */
+    int trace_rows;             /* rows of noise_pred_out / latents_out */
+    int step_noise_rows;        /* rows of step_noise */
 } sde_txt2img_opts;
 
 void sde_txt2img_opts_default(sde_txt2img_opts* o);

@@ -252,19 +252,24 @@ class DPMSolverMultistep(_Base):
 
     REFERENCE_QUIRK (``reference_quirks=True``, the parity default): ``lower_order_nums`` is
     never incremented (:118,206,347,369) so *every* step takes the first-order update.
-    ``reference_quirks=False`` gives the true multistep DPM-Solver++ 2M (midpoint) — a named,
-    separate mode, never the parity default (SURVEY.md §3.3 decision).
+    ``reference_quirks=False`` gives the multistep solver the code describes (second order :259-285,
+    third order :288-326) -- a named, separate mode, never the parity default (SURVEY.md §3.3 decision).
+    ``algorithm_type`` ("dpmsolver++" | "dpmsolver", :30-36) and ``solver_type`` ("midpoint" | "heun",
+    :43-49) follow the config struct (:71-74); ``algorithm_type`` is live in the quirk mode too
+    (convert_model_output :232-244, first-order formula :255).
     """
 
     kind = "dpmpp"
 
     def __init__(self, T=1000, beta_start=0.00085, beta_end=0.012, schedule="scaled_linear",
-                 prediction_type="epsilon", solver_order=2, reference_quirks=True):
+                 prediction_type="epsilon", solver_order=2, reference_quirks=True,
+                 algorithm_type="dpmsolver++", solver_type="midpoint", lower_order_final=True):
         _check_ctor(T, beta_start, beta_end)
         self.T = T
         self.prediction_type = prediction_type
         self.solver_order = solver_order
         self.reference_quirks = reference_quirks
+        self.algorithm_type, self.solver_type, self.lower_order_final = algorithm_type, solver_type, lower_order_final
         ac = self.alphas_cumprod = alphas_cumprod_of(make_betas(T, beta_start, beta_end, schedule))
         self.alpha_t = np.sqrt(ac).astype(np.float32)
         self.sigma_t = np.sqrt((f32(1.0) - ac).astype(np.float32)).astype(np.float32)
@@ -284,51 +289,90 @@ class DPMSolverMultistep(_Base):
         return sample.astype(np.float32).copy()
 
     def convert_model_output(self, mo, t: int, sample):
-        """:211-231 (DPMSolverPlusPlus branch)"""
+        """:211-246"""
         a, s = self.alpha_t[t], self.sigma_t[t]
+        if self.algorithm_type == "dpmsolver++":
+            if self.prediction_type == "epsilon":
+                return ((sample - s * mo) / a).astype(np.float32)
+            if self.prediction_type == "sample":
+                return mo.astype(np.float32).copy()
+            return (a * sample - s * mo).astype(np.float32)  # v_prediction
         if self.prediction_type == "epsilon":
-            return ((sample - s * mo) / a).astype(np.float32)
-        if self.prediction_type == "sample":
             return mo.astype(np.float32).copy()
-        return (a * sample - s * mo).astype(np.float32)  # v_prediction
+        if self.prediction_type == "sample":
+            return ((sample - a * mo) / s).astype(np.float32)
+        return (a * mo + s * sample).astype(np.float32)
+
+    def _exp_term(self, h):
+        """exp(-h) - 1 (D++) or exp(h) - 1 (DPMSolver), as every update formula spells it"""
+        if self.algorithm_type == "dpmsolver++":
+            return f32(f32(np.exp(f32(-h))) - f32(1.0))
+        return f32(f32(np.exp(f32(h))) - f32(1.0))
 
     def first_order_coeffs(self, t: int, prev_t: int):
-        """:248-254 → (c_sample, c_x0) with prev = c_sample*sample - c_x0*x0"""
+        """:248-257 → (c_sample, c_m0, h) with prev = c_sample*sample - c_m0*m0"""
         lam_t, lam_s = self.lambda_t[prev_t], self.lambda_t[t]
-        a_t = self.alpha_t[prev_t]
-        s_t, s_s = self.sigma_t[prev_t], self.sigma_t[t]
         h = f32(lam_t - lam_s)
-        return f32(s_t / s_s), f32(a_t * f32(f32(np.exp(f32(-h))) - f32(1.0))), h
+        ex = self._exp_term(h)
+        if self.algorithm_type == "dpmsolver++":
+            return f32(self.sigma_t[prev_t] / self.sigma_t[t]), f32(self.alpha_t[prev_t] * ex), h
+        return f32(self.alpha_t[prev_t] / self.alpha_t[t]), f32(self.sigma_t[prev_t] * ex), h
 
     def step(self, model_output, t, sample, noise=None):
         """:350-380"""
         t = int(t)
+        n = len(self.timesteps)
         i = _position(self.timesteps, t)
-        last = i == len(self.timesteps) - 1
+        last = i == n - 1
         prev_t = 0 if last else int(self.timesteps[i + 1])
-        lower_final = last and len(self.timesteps) < 15
-        lower_second = (i == len(self.timesteps) - 2) and len(self.timesteps) < 15
-        x0 = self.convert_model_output(model_output, t, sample)
-        self.model_outputs.append(x0)  # only ever pushed (:363-367) — grows; harmless here
-        if self.reference_quirks:
+        lower_final = last and self.lower_order_final and n < 15
+        lower_second = (i == n - 2) and self.lower_order_final and n < 15
+        m0 = self.convert_model_output(model_output, t, sample)
+        self.model_outputs.append(m0)  # only ever pushed (:363-367) — grows; harmless here
+        cs, c0, h = self.first_order_coeffs(t, prev_t)
+        pp = self.algorithm_type == "dpmsolver++"
+        outer = self.alpha_t[prev_t] if pp else self.sigma_t[prev_t]
+        ex = self._exp_term(h)
+        first = self.solver_order == 1 or self.lower_order_nums < 1 or lower_final
+        if not self.reference_quirks and h == 0:
+            # "fixed" mode: the final timestep 0 has prev_timestep 0, h == 0, and the multistep formulas divide by h;
+            # the first-order update is the identity there (not a reference behaviour: the reference never gets here)
             first = True
-        else:
-            first = self.solver_order == 1 or self.lower_order_nums < 1 or lower_final
         if first:
-            cs, cx, _ = self.first_order_coeffs(t, prev_t)
-            prev = (cs * sample - cx * x0).astype(np.float32)
-        else:
-            # true 2M midpoint (:259-278); only reachable with reference_quirks=False
-            s0, s1 = t, int(self.timesteps[i - 1])
-            m0, m1 = self.model_outputs[-1], self.model_outputs[-2]
-            lam_t, lam_s0, lam_s1 = self.lambda_t[prev_t], self.lambda_t[s0], self.lambda_t[s1]
-            a_t = self.alpha_t[prev_t]
-            s_t, s_s0 = self.sigma_t[prev_t], self.sigma_t[s0]
-            h, h0 = f32(lam_t - lam_s0), f32(lam_s0 - lam_s1)
+            prev = (cs * sample - c0 * m0).astype(np.float32)
+        elif self.solver_order == 2 or self.lower_order_nums < 2 or lower_second:
+            # :259-285; only reachable with reference_quirks=False
+            s1 = int(self.timesteps[i - 1])
+            m1 = self.model_outputs[-2]
+            h0 = f32(self.lambda_t[t] - self.lambda_t[s1])
             r0 = f32(h0 / h)
             d1 = (f32(f32(1.0) / r0) * (m0 - m1)).astype(np.float32)
-            c = f32(a_t * f32(f32(np.exp(f32(-h))) - f32(1.0)))
-            prev = (f32(s_t / s_s0) * sample - c * m0 - f32(f32(0.5) * c) * d1).astype(np.float32)
+            if self.solver_type == "midpoint":
+                prev = (cs * sample - c0 * m0 - f32(f32(0.5) * c0) * d1).astype(np.float32)
+            elif pp:
+                prev = (cs * sample - c0 * m0 + f32(outer * f32(f32(ex / h) + f32(1.0))) * d1).astype(np.float32)
+            else:
+                prev = (cs * sample - c0 * m0 - f32(outer * f32(f32(ex / h) - f32(1.0))) * d1).astype(np.float32)
+        else:
+            # :288-326
+            s1, s2 = int(self.timesteps[i - 1]), int(self.timesteps[i - 2])
+            m1, m2 = self.model_outputs[-2], self.model_outputs[-3]
+            h0 = f32(self.lambda_t[t] - self.lambda_t[s1])
+            h1 = f32(self.lambda_t[s1] - self.lambda_t[s2])
+            r0, r1 = f32(h0 / h), f32(h1 / h)
+            d10 = (f32(f32(1.0) / r0) * (m0 - m1)).astype(np.float32)
+            d11 = (f32(f32(1.0) / r1) * (m1 - m2)).astype(np.float32)
+            d1 = (d10 + f32(r0 / f32(r0 + r1)) * (d10 - d11)).astype(np.float32)
+            d2 = (f32(f32(1.0) / f32(r0 + r1)) * (d10 - d11)).astype(np.float32)
+            h2 = f32(h * h)
+            if pp:
+                c1 = f32(outer * f32(f32(ex / h) + f32(1.0)))
+                c2 = f32(outer * f32(f32(f32(ex + h) / h2) - f32(0.5)))
+                prev = (cs * sample - c0 * m0 + c1 * d1 - c2 * d2).astype(np.float32)
+            else:
+                c1 = f32(outer * f32(f32(ex / h) - f32(1.0)))
+                c2 = f32(outer * f32(f32(f32(ex - h) / h2) - f32(0.5)))
+                prev = (cs * sample - c0 * m0 - c1 * d1 - c2 * d2).astype(np.float32)
         if not self.reference_quirks and self.lower_order_nums < self.solver_order:
             self.lower_order_nums += 1
         return prev

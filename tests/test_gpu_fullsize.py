@@ -124,6 +124,66 @@ def test_sd15_batch_invariance_and_determinism(sd15):
     assert rel_l2(part, full[1:3]) < 2e-3   # tile shapes change with the batch, so fp32 summation order may differ
 
 
+# ---------------------------------------------------------------------------------------------- the benchmarked dispatch
+def test_sd15_unet_forward_batch16(sd15):
+    """bench.py's UNet call: batch 16 (B = 8 prompts under CFG), where launch_gemm picks other kernels and split factors than
+    at batch 1-4 (256x320 tiles at 64x64, the 12-wave 256x160 kernel + split-K at 32x32 .. 8x8).  All 16 samples against the
+    fp32 oracle, per sample and overall."""
+    from oracle import unet_ref
+    pipe, uw, ucfg, _, _ = sd15
+    rng = np.random.default_rng(1616)
+    x = (rng.standard_normal((16, 4, 64, 64)) * rng.uniform(0.5, 3.0, (16, 1, 1, 1))).astype(np.float32)
+    ehs = (rng.standard_normal((16, 77, 768)) * 0.5).astype(np.float32)
+    with torch.no_grad():
+        ref = unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), 412.0, torch.from_numpy(ehs)).numpy()
+    got = pipe.unet(x, 412.0, ehs)
+    assert np.isfinite(got).all()
+    assert rel_l2(got, ref) < 1e-2, rel_l2(got, ref)
+    worst = max(rel_l2(got[i], ref[i]) for i in range(16))
+    assert worst < 1e-2, worst
+
+
+def _loop_at_config_batch(pipe, uw, ucfg, vw, vcfg, kind, B, S, D, h, w, steps, guidance, sched_kw=None, oracle_kw=None, pick=None):
+    """Runs the ENGINE at the configuration's full batch (so its kernels, tiles and split factors are the benchmarked ones) and the
+    CPU oracle on the samples `pick` only: prompts are independent (no batch-wide reduction without rescale_cfg), so a sample's
+    oracle trajectory does not depend on its neighbours.  Checks per-step CFG-combined noise prediction and the decoded image."""
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionTxt2ImgOptions
+    from oracle import schedulers as S_, txt2img as T, unet_ref
+    pick = pick if pick is not None else [0, B - 1]
+    rng = np.random.default_rng(B * 1000 + S)
+    ehs = (rng.standard_normal((2 * B, S, D)) * 0.5).astype(np.float32)
+    init = rng.standard_normal((B, 4, h, w)).astype(np.float32)
+    noise = rng.standard_normal((steps + 2, B, 4, h, w)).astype(np.float32)
+    opts = StableDiffusionTxt2ImgOptions(height=h * 8, width=w * 8, guidance_scale=guidance, steps=steps, text_embeddings=ehs, batch_size=B,
+                                         init_latents=init, step_noise=noise)
+    res = opts.run(pipe, N.BY_NAME[kind].stable_diffusion_v1_optimized_default(**(sched_kw or {})), trace=True)
+    sub = np.concatenate([ehs[pick], ehs[[B + p for p in pick]]], 0)
+    unet = lambda x, t, e: unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), t, torch.from_numpy(e)).numpy()
+    with torch.no_grad():
+        ref = T.run(unet, S_.make(kind, **(oracle_kw or {})), sub, init[pick], steps, guidance, None, noise[:, pick])
+        ref_img = unet_ref.decode_latents(vw, vcfg, torch.from_numpy(ref["final"])).numpy()
+    assert res.unet_calls == len(ref["timesteps"])
+    for i in range(res.unet_calls):
+        for j, p in enumerate(pick):
+            err = rel_l2(res.noise_pred[i][p], ref["noise_pred"][i][j])
+            assert err < 1e-2, (kind, i, p, err)
+    assert np.isfinite(res.images).all()
+    assert psnr(res.images[pick], ref_img) >= 35.0, psnr(res.images[pick], ref_img)
+
+
+def test_config3_euler_a_batch8_two_steps(sd15):
+    """BASELINE configs[2]: Euler-a, B = 8 (UNet batch 16), CFG 7.5, 512x512."""
+    pipe, uw, ucfg, vw, vcfg = sd15
+    _loop_at_config_batch(pipe, uw, ucfg, vw, vcfg, "euler_a", 8, 77, 768, 64, 64, 2, 7.5)
+
+
+def test_config5_lms_batch16_long_prompt_two_steps(sd15):
+    """BASELINE configs[4]: LMS, B = 16 (UNet batch 32), 227-token weighted prompts, + 16 VAE decodes."""
+    pipe, uw, ucfg, vw, vcfg = sd15
+    _loop_at_config_batch(pipe, uw, ucfg, vw, vcfg, "lms", 16, 227, 768, 64, 64, 2, 7.5)
+
+
 # ---------------------------------------------------------------------------------------------- BASELINE configs[3] at full size
 SD21_DIR = os.environ.get("SDE_SD21_MODEL_DIR", "/tmp/sde_cfg_sd21_f16")
 
@@ -152,5 +212,26 @@ def test_sd21_fullsize_unet_forward_768():
         got = pipe.unet(x, 733.0, ehs)
         assert np.isfinite(got).all()
         assert rel_l2(got, ref) < 1e-2, rel_l2(got, ref)
+    finally:
+        pipe.close()
+
+
+def test_config4_sd21_ddim_v_batch4_loop():
+    """BASELINE configs[3]: SD v2.1 768x768 (96x96 latents), v-prediction, DDIM, B = 4 (UNet batch 8): "3 steps" = 2 UNet calls
+    (ddim.rs:184 yields n - 1 timesteps)."""
+    from diffusers_amd import modelgen
+    from diffusers_amd.pipeline import StableDiffusionPipeline
+    from oracle import model_dir
+    if not os.path.exists(os.path.join(SD21_DIR, ".complete")):
+        modelgen.write_model_dir(SD21_DIR, modelgen.sd21_unet_config(), modelgen.vae_config(), seed=42, dtype=np.float16)
+        open(os.path.join(SD21_DIR, ".complete"), "w").write("ok")
+    pipe = StableDiffusionPipeline(SD21_DIR)
+    try:
+        uw, ucfg = model_dir.load_unet(SD21_DIR)
+        vw, vcfg = model_dir.load_vae_decoder(SD21_DIR)
+        t = lambda d: {k: torch.from_numpy(v) for k, v in d.items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        _loop_at_config_batch(pipe, t(uw), ucfg, t(vw), vcfg, "ddim", 4, 77, 1024, 96, 96, 3, 7.5,
+                              sched_kw=dict(prediction_type="v_prediction"), oracle_kw=dict(prediction_type="v_prediction"), pick=[3])
     finally:
         pipe.close()

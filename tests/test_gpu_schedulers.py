@@ -74,6 +74,44 @@ def test_true_dpmpp_2m_mode():
         assert np.abs(x - xo).max() <= 2e-5 * max(1.0, np.abs(xo).max())
 
 
+@pytest.mark.parametrize("algo", ["dpmsolver++", "dpmsolver"])
+@pytest.mark.parametrize("pred", ["epsilon", "sample", "v_prediction"])
+def test_dpm_algorithm_type_in_parity_mode(algo, pred):
+    """DPMSolverAlgorithmType (dpm_solver_multistep.rs:30-36) is live in the reference even with its first-order quirk:
+    convert_model_output (:232-244) and the first-order formula (:255)."""
+    from diffusers_amd import schedulers as N
+    from oracle import schedulers as S
+    rng = np.random.default_rng(16)
+    o = S.make("dpmpp", algorithm_type=algo, prediction_type=pred); o.set_timesteps(12)
+    s = N.DPMSolverMultistepScheduler.stable_diffusion_v1_optimized_default(algorithm_type=algo, prediction_type=pred); s.set_timesteps(12)
+    x = xo = rng.standard_normal((1, 4, 8, 8)).astype(np.float32)
+    for t in o.timesteps:
+        e = rng.standard_normal(x.shape).astype(np.float32)
+        x, xo = s.step(e, float(t), x), o.step(e, t, xo)
+        assert np.abs(x - xo).max() <= 1e-5 * max(1.0, np.abs(xo).max()), (algo, pred, t)
+
+
+@pytest.mark.parametrize("order,algo,solver,n", [(2, "dpmsolver++", "heun", 20), (2, "dpmsolver", "midpoint", 20), (2, "dpmsolver", "heun", 20),
+                                                 (3, "dpmsolver++", "midpoint", 20), (3, "dpmsolver", "midpoint", 20),
+                                                 (3, "dpmsolver++", "midpoint", 10), (2, "dpmsolver++", "midpoint", 10)])
+def test_dpm_multistep_variants(order, algo, solver, n):
+    """reference_quirks=0: the second-order (Midpoint / Heun, :259-285) and third-order (:288-326) multistep updates of both
+    algorithm types, which the reference's code describes and never reaches; n < 15 exercises lower_order_final (:359-360)."""
+    from diffusers_amd import schedulers as N
+    from oracle import schedulers as S
+    rng = np.random.default_rng(60 + order)
+    o = S.make("dpmpp", reference_quirks=False, solver_order=order, algorithm_type=algo, solver_type=solver); o.set_timesteps(n)
+    s = N.DPMSolverMultistepScheduler.stable_diffusion_v1_optimized_default(reference_quirks=0, solver_order=order, algorithm_type=algo,
+                                                                            solver_type=solver)
+    s.set_timesteps(n)
+    x = xo = rng.standard_normal((1, 4, 8, 8)).astype(np.float32)
+    for t in o.timesteps:
+        e = (rng.standard_normal(x.shape) * 0.5).astype(np.float32)
+        x, xo = s.step(e, float(t), x), o.step(e, t, xo)
+        assert np.isfinite(xo).all()
+        assert np.abs(x - xo).max() <= 5e-5 * max(1.0, np.abs(xo).max()), (order, algo, solver, t)
+
+
 def test_scheduler_misuse_errors():
     from diffusers_amd import _lib, schedulers as N
     s = N.EulerDiscreteScheduler.stable_diffusion_v1_optimized_default(); s.set_timesteps(20)
@@ -89,6 +127,10 @@ def test_scheduler_misuse_errors():
     d = N.DDPMScheduler.stable_diffusion_v1_optimized_default(prediction_type="v_prediction"); d.set_timesteps(20)
     with pytest.raises(_lib.SdeError):   # ddpm.rs:206 unimplemented!()
         d.step(x, float(d.timesteps()[0]), x, x)
+    with pytest.raises(_lib.SdeError, match="solver_order"):
+        N.DPMSolverMultistepScheduler.stable_diffusion_v1_optimized_default(solver_order=4)
+    with pytest.raises(_lib.SdeError):   # one training timestep: the reference's interpolator panics on its bounds check
+        N.EulerDiscreteScheduler(num_train_timesteps=1).set_timesteps(1)
 
 
 def test_add_noise():
