@@ -150,20 +150,21 @@ void launch_approx_decode(const LaunchCtx& ctx, const float* lat, float* img, in
 struct RepackDev {
     const void* src; int src_is_f16;
     int O, I, KH, KW, in_out;
-    half_t* dst; int dst_row0, Ipad, i0, Kdst, geglu_half, geglu_pair;
+    half_t* dst; int dst_row0, Ipad, i0, Kdst, geglu_half, geglu_pair, src_i0, nI;
 };
 __global__ void repack_kernel(RepackDev a)
 {
-    long long total = (long long)a.O * a.I * a.KH * a.KW;
+    long long total = (long long)a.O * a.nI * a.KH * a.KW;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        // idx enumerates the DESTINATION order (o, tap, i) so that writes coalesce
-        int i = (int)(idx % a.I);
-        long long t = idx / a.I;
+        // idx enumerates the DESTINATION order (o, tap, i) so that writes coalesce; i counts from the first copied source channel
+        int i = (int)(idx % a.nI);
+        long long t = idx / a.nI;
         int tap = (int)(t % (a.KH * a.KW));
         int o = (int)(t / (a.KH * a.KW));
+        const int is = a.src_i0 + i;                                                // source channel
         long long s;
-        if (a.in_out) s = (long long)i * a.O + o;                                   // [I][O] (onnx::MatMul_n)
-        else s = (((long long)o * a.I + i) * a.KH * a.KW) + tap;                    // OIHW / [O][I]
+        if (a.in_out) s = (long long)is * a.O + o;                                  // [I][O] (onnx::MatMul_n)
+        else s = (((long long)o * a.I + is) * a.KH * a.KW) + tap;                   // OIHW / [O][I]
         float v = a.src_is_f16 ? (float)((const half_t*)a.src)[s] : ((const float*)a.src)[s];
         int row = o;
         if (a.geglu_half > 0) {
@@ -180,8 +181,10 @@ __global__ void repack_kernel(RepackDev a)
 }
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& r)
 {
-    RepackDev a{r.src, r.src_is_f16, r.O, r.I, r.KH, r.KW, r.in_out, r.dst, r.dst_row0, r.Ipad, r.i0, r.Kdst, r.geglu_half, r.geglu_pair};
-    long long total = (long long)a.O * a.I * a.KH * a.KW;
+    const int nI = r.src_I > 0 ? r.src_I : r.I;
+    SDE_REQUIRE(r.src_i0 >= 0 && r.src_i0 + nI <= r.I, SDE_ERR_INVALID_ARGUMENT, "repack: source channel range");
+    RepackDev a{r.src, r.src_is_f16, r.O, r.I, r.KH, r.KW, r.in_out, r.dst, r.dst_row0, r.Ipad, r.i0, r.Kdst, r.geglu_half, r.geglu_pair, r.src_i0, nI};
+    long long total = (long long)a.O * nI * a.KH * a.KW;
     hipLaunchKernelGGL(repack_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 8192)), dim3(256), 0, ctx.stream, a);
     HIP_CHECK(hipGetLastError());
 }

@@ -138,6 +138,7 @@ struct sde_engine {
     DevBuf arena_buf, zeros, splitk_ws, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps, rescale_ws;
     PinnedBuf noise_host;
     std::unique_ptr<PreviewLane> preview;
+    long long split_max_hw = 1LL << 40;   // UNet trunk as split fp16 at every level (Exec::split); SDE_SPLIT_MAX_HW: tuning hook (0 = off)
     std::vector<half_t*> kv_ptrs;
     std::mutex mu;  // one forward at a time per engine (reference: Session is Send+Sync; here calls serialize)
     std::atomic<std::thread::id> owner{std::thread::id()};  // thread inside a locked call (re-entry from a callback is refused)
@@ -198,14 +199,14 @@ static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w,
     const long long key = ((long long)N << 40) ^ ((long long)h << 28) ^ ((long long)w << 16) ^ S;
     if (key != e->unet_key) {
         Arena dry; dry.dry = true;
-        Exec dx{e->ctx, &dry};
+        Exec dx{e->ctx, &dry, e->split_max_hw};
         std::vector<half_t*> fake((size_t)e->unet.n_transformers, (half_t*)nullptr);
         e->unet.forward(dx, nullptr, N, h, w, t, nullptr, S, fake.data(), true, nullptr);
         e->unet_peak = dry.peak; e->unet_key = key;
     }
     ensure_arena(e, std::max(e->unet_peak, e->vae_peak));
     e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false;
-    Exec ex{e->ctx, &e->arena};
+    Exec ex{e->ctx, &e->arena, e->split_max_hw};
     e->unet.forward(ex, x_packed, N, h, w, t, ehs_h, S, e->kv_ptrs.data(), fill_kv, out);
 }
 
@@ -327,6 +328,7 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
         e->splitk_ws.ensure((size_t)64 << 20);
         e->ctx.splitk_ws = e->splitk_ws.as<float>(); e->ctx.splitk_ws_bytes = e->splitk_ws.cap;
         if (const char* sk = getenv("SDE_SPLITK")) e->ctx.splitk_force = atoi(sk);   // tuning hook (0 = heuristic, 1 = off)
+        if (const char* sp = getenv("SDE_SPLIT_MAX_HW")) e->split_max_hw = atoll(sp);
         e->wb.ctx = e->ctx; e->wb.ctx.prof = nullptr;
         if (o.load_unet && !unet_path.empty()) {
             OnnxModel m; WeightMap w;

@@ -113,8 +113,8 @@ void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows
 // y = LayerNorm(S32 + A + B) with the sum formed and kept in fp32 (any of the three may be null, not all); S32_out (optional) receives the sum
 void launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows, int C,
                           const float* gamma, const float* beta, float eps);
-// Y = half(S32 + A + B), n elements (n % 8 == 0)
-void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, int64_t n);
+// Y = half(S32 + A + B), n elements (n % 8 == 0); Ylo (optional) receives the low part half(sum - Y) of a split-fp16 result
+void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, half_t* Ylo, int64_t n);
 // in-place softmax over the last dim of a [rows][cols] fp16 matrix (fp32 math)
 void launch_softmax_rows(const LaunchCtx& ctx, half_t* X, int64_t rows, int cols, int pitch);   // in place; columns [cols, pitch) become 0
 
@@ -143,6 +143,7 @@ struct RepackArgs {
     int Kdst = 0;                              // dst row length
     int geglu_half = 0;                        // >0: row o -> interleaved row (16-block value/gate), value = geglu_half
     int geglu_pair = 0;                        // with geglu_half: pairwise interleave instead (value_j -> 2j, gate_j -> 2j+1)
+    int src_i0 = 0, src_I = 0;                 // copy only source channels [src_i0, src_i0 + src_I) (src_I = 0: all I of them)
 };
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& a);
 

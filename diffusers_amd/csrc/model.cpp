@@ -106,10 +106,45 @@ DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std
     return L;
 }
 
+DevLinear WeightBuilder::linear_dup(const std::string& name, const std::vector<std::string>& bias_names, int i0, int n)
+{
+    DevLinear L;
+    const BoundTensor& b = get(name);
+    const auto& d = b.t->dims;
+    SDE_REQUIRE(d.size() == 2 || (d.size() == 4 && d[2] == 1 && d[3] == 1), SDE_ERR_MODEL, "linear_dup: " + name + " is not a 1x1 / Linear weight");
+    const int O = (int)(d.size() == 4 ? d[0] : b.out_dim()), I = (int)(d.size() == 4 ? d[1] : b.in_dim());
+    SDE_REQUIRE(i0 >= 0 && n > 0 && i0 + n <= I, SDE_ERR_MODEL, "linear_dup: channel range of " + name);
+    L.taps = 1; L.Cin = 2 * n; L.K = 2 * n; L.N = O; L.Npad = gemm_npad(O);
+    const size_t wbytes = (size_t)L.Npad * L.K * sizeof(half_t);
+    L.W = (half_t*)dmalloc(wbytes);
+    HIP_CHECK(hipMemsetAsync(L.W, 0, wbytes, ctx.stream));
+    const size_t nbytes = (size_t)b.t->numel() * (b.t->data_type == 1 ? 4 : 2);
+    if (nbytes > staging_cap) {
+        if (staging) { HIP_CHECK(hipStreamSynchronize(ctx.stream)); HIP_CHECK(hipFree(staging)); }
+        staging_cap = std::max(nbytes, (size_t)64 << 20);
+        HIP_CHECK(hipMalloc(&staging, staging_cap));
+    }
+    HIP_CHECK(hipMemcpyAsync(staging, b.t->data, nbytes, hipMemcpyHostToDevice, ctx.stream));
+    for (int rep = 0; rep < 2; ++rep) {
+        RepackArgs r;
+        r.src = staging; r.src_is_f16 = b.t->data_type == 10; r.O = O; r.I = I; r.KH = r.KW = 1; r.in_out = (d.size() == 2 && b.in_out) ? 1 : 0;
+        r.dst = L.W; r.dst_row0 = 0; r.Ipad = 2 * n; r.i0 = rep * n; r.Kdst = L.K; r.src_i0 = i0; r.src_I = n;
+        launch_repack(ctx, r);
+    }
+    if (!bias_names.empty()) {
+        std::vector<float> bias;
+        for (auto& bn : bias_names) { auto v = host_f32(bn); bias.insert(bias.end(), v.begin(), v.end()); }
+        SDE_REQUIRE((int)bias.size() == O, SDE_ERR_MODEL, "bias size mismatch for " + name);
+        L.bias = upload_f32(bias);
+    }
+    return L;   // a second layout of weights already counted: params unchanged
+}
+
 // ------------------------------------------------------------------------------------------ forward helpers
 namespace {
 
-struct Act { half_t* p; int C, H, W; };  // NHWC activation [NB*H*W][C]
+// NHWC activation [NB*H*W][C]; lo != null: split fp16, value = hi + lo (kernels.h), lo has hi's layout
+struct Tn { half_t* hi = nullptr; half_t* lo = nullptr; };
 
 void run_gemm(Exec& ex, GemmArgs& g)
 {
@@ -119,12 +154,12 @@ void run_gemm(Exec& ex, GemmArgs& g)
 
 // linear / 1x1 conv over rows
 void linear(Exec& ex, const DevLinear& L, const half_t* A, int lda, int M, half_t* D, int ldd, const half_t* R = nullptr, int ldr = 0,
-            const half_t* A1 = nullptr, int C0 = 0, int C1 = 0, int lda1 = 0)
+            const half_t* A1 = nullptr, int C0 = 0, int C1 = 0, int lda1 = 0, const half_t* Rlo = nullptr, half_t* Dlo = nullptr)
 {
     GemmArgs g;
     g.A0 = A; g.lda0 = lda; g.C0 = A1 ? C0 : L.K; g.A1 = A1; g.C1 = A1 ? C1 : 0; g.lda1 = lda1;
     g.M = M; g.N = L.N; g.K = L.K; g.taps = 1;
-    g.W = L.W; g.Npad = L.Npad; g.bias = L.bias; g.R = R; g.ldr = ldr; g.D = D; g.ldd = ldd;
+    g.W = L.W; g.Npad = L.Npad; g.bias = L.bias; g.R = R; g.ldr = ldr; g.D = D; g.ldd = ldd; g.Rlo = Rlo; g.Dlo = Dlo;
     g.epi = L.geglu ? (L.geglu_pair ? EPI_GEGLU_PAIR : EPI_GEGLU) : EPI_STD;
     g.gelu_tanh = L.gelu_tanh ? 1 : 0;
     SDE_REQUIRE(L.taps == 1 && g.C0 + g.C1 == L.K, SDE_ERR_MODEL, "linear: operand width mismatch");
@@ -136,7 +171,8 @@ void linear(Exec& ex, const DevLinear& L, const half_t* A, int lda, int M, half_
 // `forward_upsample_size` case of the exported UNet (F.interpolate(size = skip size), ONNX Resize asymmetric / floor): for those
 // sizes floor(y * H / Hu) == y >> 1 for every y < Hu, i.e. the 2x upsample cropped by one row / column.
 void conv3x3(Exec& ex, const DevLinear& L, const half_t* A, int C, int NB, int H, int W, int stride, int ups, half_t* D, int ldd,
-             const float* bias, const half_t* R, int ldr, int epi = EPI_STD, float* Df = nullptr, int Hu = 0, int Wu = 0)
+             const float* bias, const half_t* R, int ldr, int epi = EPI_STD, float* Df = nullptr, int Hu = 0, int Wu = 0,
+             const half_t* Rlo = nullptr, half_t* Dlo = nullptr)
 {
     GemmArgs g;
     g.A0 = A; g.lda0 = C; g.C0 = C;
@@ -145,17 +181,18 @@ void conv3x3(Exec& ex, const DevLinear& L, const half_t* A, int C, int NB, int H
     SDE_REQUIRE(!ups || ((g.Hi + 1) / 2 == H && (g.Wi + 1) / 2 == W), SDE_ERR_INVALID_ARGUMENT, "conv3x3: upsample target must be 2x or 2x - 1");
     g.Ho = (g.Hi - 1) / stride + 1; g.Wo = (g.Wi - 1) / stride + 1;
     g.M = NB * g.Ho * g.Wo; g.N = L.N; g.K = L.K;
-    g.W = L.W; g.Npad = L.Npad; g.bias = bias; g.R = R; g.ldr = ldr; g.D = D; g.Df = Df; g.ldd = ldd; g.epi = epi;
+    g.W = L.W; g.Npad = L.Npad; g.bias = bias; g.R = R; g.ldr = ldr; g.D = D; g.Df = Df; g.ldd = ldd; g.epi = epi; g.Rlo = Rlo; g.Dlo = Dlo;
     SDE_REQUIRE(L.taps == 9 && L.Cin == C, SDE_ERR_MODEL, "conv3x3: channel mismatch");
     run_gemm(ex, g);
 }
 
-void groupnorm(Exec& ex, const DevNorm& n, const half_t* X0, int C0, const half_t* X1, int C1, int NB, int HW, float eps, bool silu, half_t* Y)
+void groupnorm(Exec& ex, const DevNorm& n, const half_t* X0, int C0, const half_t* X1, int C1, int NB, int HW, float eps, bool silu, half_t* Y,
+               const half_t* X0lo = nullptr, const half_t* X1lo = nullptr)
 {
     SDE_REQUIRE(n.C == C0 + C1, SDE_ERR_MODEL, "groupnorm: channel mismatch");
     GroupNormArgs a;
     a.X0 = X0; a.X1 = X1; a.C0 = C0; a.C1 = C1; a.NB = NB; a.HW = HW; a.groups = 32; a.eps = eps; a.gamma = n.gamma; a.beta = n.beta;
-    a.silu = silu; a.Y = Y;
+    a.silu = silu; a.Y = Y; a.X0lo = X0lo; a.X1lo = X1lo;
     size_t m = ex.arena->mark();
     a.ws = ex.arena->get<float>(groupnorm_ws_floats(NB, C0 + C1, HW));
     if (!ex.dry()) launch_groupnorm(ex.ctx, a);
@@ -168,27 +205,42 @@ void layernorm(Exec& ex, const DevNorm& n, const half_t* X, half_t* Y, int rows)
     launch_layernorm(ex.ctx, X, Y, rows, n.C, n.gamma, n.beta, 1e-5f);
 }
 
-// ResnetBlock2D: x (optionally a concat x0|x1) -> out [NB*H*W][cout]
-half_t* resnet(Exec& ex, const ResnetW& r, const half_t* x0, int c0, const half_t* x1, int c1, int NB, int H, int W, float eps,
-               const float* tbias)
+// ResnetBlock2D: x (optionally a concat x0|x1) -> out [NB*H*W][cout].  Where the level is split (Exec::split), the output and the
+// shortcut convolution's output are split fp16: neither is an MFMA operand of conv1 / conv2, they only feed GroupNorm and residual
+// adds, and their fp16 rounding was the largest term of the engine-vs-fp32 error (tools/error_budget.py).
+Tn resnet(Exec& ex, const ResnetW& r, Tn x0, int c0, Tn x1, int c1, int NB, int H, int W, float eps, const float* tbias)
 {
     const int M = NB * H * W, cin = c0 + c1;
+    const bool sp = ex.split(H * W);
     SDE_REQUIRE(cin == r.cin, SDE_ERR_MODEL, "resnet: input channel mismatch");
-    half_t* out = ex.arena->get<half_t>((size_t)M * r.cout);
+    Tn out;
+    out.hi = ex.arena->get<half_t>((size_t)M * r.cout);
+    if (sp) out.lo = ex.arena->get<half_t>((size_t)M * r.cout);
     const size_t mk = ex.arena->mark();
     half_t* hn = ex.arena->get<half_t>((size_t)M * cin);
-    groupnorm(ex, r.n1, x0, c0, x1, c1, NB, H * W, eps, true, hn);
+    groupnorm(ex, r.n1, x0.hi, c0, x1.hi, c1, NB, H * W, eps, true, hn, x0.lo, x1.lo);
     half_t* h1 = ex.arena->get<half_t>((size_t)M * r.cout);
     conv3x3(ex, r.conv1, hn, cin, NB, H, W, 1, 0, h1, r.cout, r.has_temb ? tbias + r.temb_off : r.conv1.bias, nullptr, 0);
     half_t* hn2 = ex.arena->get<half_t>((size_t)M * r.cout);
     groupnorm(ex, r.n2, h1, r.cout, nullptr, 0, NB, H * W, eps, true, hn2);
-    const half_t* sc = x0;
+    Tn sc = x0;
     if (r.has_shortcut) {
-        half_t* s = ex.arena->get<half_t>((size_t)M * r.cout);
-        linear(ex, r.shortcut, x0, c0, M, s, r.cout, nullptr, 0, x1, c0, c1, c1);
-        sc = s;
-    } else SDE_REQUIRE(x1 == nullptr && cin == r.cout, SDE_ERR_MODEL, "resnet: identity shortcut with changing width");
-    conv3x3(ex, r.conv2, hn2, r.cout, NB, H, W, 1, 0, out, r.cout, r.conv2.bias, sc, r.cout);
+        sc.hi = ex.arena->get<half_t>((size_t)M * r.cout);
+        sc.lo = sp ? ex.arena->get<half_t>((size_t)M * r.cout) : nullptr;
+        if (sp && r.has_sc2 && x0.lo && !x1.hi) {
+            // split-fp16 operand: K = [x.hi | x.lo] against [W | W]
+            linear(ex, r.shortcut_a2, x0.hi, c0, M, sc.hi, r.cout, nullptr, 0, x0.lo, c0, c0, c0, nullptr, sc.lo);
+        } else if (sp && r.has_sc2 && x0.lo && x1.lo && c0 == r.sc_c0) {
+            // concat input: W_h [h.hi | h.lo] (no bias) chained into W_s [s.hi | s.lo] + bias as a split-fp16 residual
+            Tn part;
+            part.hi = ex.arena->get<half_t>((size_t)M * r.cout);
+            part.lo = ex.arena->get<half_t>((size_t)M * r.cout);
+            linear(ex, r.shortcut_a2, x0.hi, c0, M, part.hi, r.cout, nullptr, 0, x0.lo, c0, c0, c0, nullptr, part.lo);
+            linear(ex, r.shortcut_b2, x1.hi, c1, M, sc.hi, r.cout, part.hi, r.cout, x1.lo, c1, c1, c1, part.lo, sc.lo);
+        } else
+            linear(ex, r.shortcut, x0.hi, c0, M, sc.hi, r.cout, nullptr, 0, x1.hi, c0, c1, c1, nullptr, sc.lo);   // operand: high parts only
+    } else SDE_REQUIRE(x1.hi == nullptr && cin == r.cout, SDE_ERR_MODEL, "resnet: identity shortcut with changing width");
+    conv3x3(ex, r.conv2, hn2, r.cout, NB, H, W, 1, 0, out.hi, r.cout, r.conv2.bias, sc.hi, r.cout, EPI_STD, nullptr, 0, 0, sc.lo, out.lo);
     ex.arena->release(mk);
     return out;
 }
@@ -204,13 +256,15 @@ void attention(Exec& ex, const half_t* Q, int ldq, const half_t* K, int ldk, con
 }
 
 // Transformer2DModel (depth 1) on NHWC tokens; conv 1x1 and Linear projections are the same contraction here.
-half_t* transformer(Exec& ex, const TransformerW& t, const half_t* x, int NB, int H, int W, const half_t* kv, int S)
+Tn transformer(Exec& ex, const TransformerW& t, Tn x, int NB, int H, int W, const half_t* kv, int S)
 {
     const int C = t.C, HW = H * W, M = NB * HW, d = C / t.heads;
-    half_t* out = ex.arena->get<half_t>((size_t)M * C);
+    Tn out;
+    out.hi = ex.arena->get<half_t>((size_t)M * C);
+    if (ex.split(HW)) out.lo = ex.arena->get<half_t>((size_t)M * C);
     const size_t mk = ex.arena->mark();
     half_t* n = ex.arena->get<half_t>((size_t)M * C);
-    groupnorm(ex, t.gn, x, C, nullptr, 0, NB, HW, 1e-6f, false, n);
+    groupnorm(ex, t.gn, x.hi, C, nullptr, 0, NB, HW, 1e-6f, false, n, x.lo);
     // The block's residual stream x0 -> x0 + attn1 -> .. + attn2 -> .. + ff is carried as an fp32 SUM and rounded to fp16 once, at
     // the end (proj_out reads it as an MFMA operand).  The branch outputs y0..y3 are plain fp16 GEMM outputs; each LayerNorm forms
     // the sum it normalises in fp32.  Rounding the stream after every residual add (three more roundings per block, 48 per UNet call)
@@ -240,8 +294,10 @@ half_t* transformer(Exec& ex, const TransformerW& t, const half_t* x, int NB, in
     half_t* y3 = y1;  // y1 is folded into s1
     linear(ex, t.ff2, g, 4 * C, M, y3, C);
     half_t* h1 = n;   // the normalised copy is dead: h1 = half(s1 + y2 + y3)
-    if (!ex.dry()) launch_sum_round(ex.ctx, s1, y2, y3, h1, (int64_t)M * C);
-    linear(ex, t.proj_out, h1, C, M, out, C, x, C);
+    half_t* h1lo = (out.lo && t.proj_out2.W) ? ex.arena->get<half_t>((size_t)M * C) : nullptr;   // proj_out reads [h1 | h1lo] against [W | W]
+    if (!ex.dry()) launch_sum_round(ex.ctx, s1, y2, y3, h1, h1lo, (int64_t)M * C);
+    if (h1lo) linear(ex, t.proj_out2, h1, C, M, out.hi, C, x.hi, C, h1lo, C, C, C, x.lo, out.lo);
+    else linear(ex, t.proj_out, h1, C, M, out.hi, C, x.hi, C, nullptr, 0, 0, 0, x.lo, out.lo);
     ex.arena->release(mk);
     return out;
 }
@@ -267,6 +323,7 @@ TransformerW build_transformer(WeightBuilder& b, const std::string& p, int heads
     t.gn = b.norm(p + ".norm");
     t.proj_in = b.linear({p + ".proj_in.weight"}, {p + ".proj_in.bias"});
     t.proj_out = b.linear({p + ".proj_out.weight"}, {p + ".proj_out.bias"});
+    t.proj_out2 = b.linear_dup(p + ".proj_out.weight", {p + ".proj_out.bias"}, 0, t.proj_out.K);
     const std::string k = p + ".transformer_blocks.0";
     t.ln1 = b.norm(k + ".norm1"); t.ln2 = b.norm(k + ".norm2"); t.ln3 = b.norm(k + ".norm3");
     t.qkv = b.linear({k + ".attn1.to_q.weight", k + ".attn1.to_k.weight", k + ".attn1.to_v.weight"}, {});
@@ -357,6 +414,31 @@ void UNetModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b, 
     }
     norm_out = b.norm("conv_norm_out");
     conv_out = b.linear({"conv_out.weight"}, {"conv_out.bias"});
+    // shortcut weights for split-fp16 operands (model.h): replay the skip-connection stack to learn each concat's split point
+    {
+        auto dup = [&](ResnetW& r, const std::string& p, int c0) {
+            if (!r.has_shortcut || c0 % 64 || (r.cin - c0) % 64) return;
+            const std::string wn = p + ".conv_shortcut.weight", bn = p + ".conv_shortcut.bias";
+            if (c0 == r.cin) r.shortcut_a2 = b.linear_dup(wn, {bn}, 0, c0);
+            else { r.shortcut_a2 = b.linear_dup(wn, {}, 0, c0); r.shortcut_b2 = b.linear_dup(wn, {bn}, c0, r.cin - c0); }
+            r.sc_c0 = c0; r.has_sc2 = true;
+        };
+        std::vector<int> skip_ch{boc[0]};
+        for (int i = 0; i < n_levels; ++i) {
+            for (int j = 0; j < layers_per_block; ++j) {
+                dup(down[i].res[j], "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), down[i].res[j].cin);
+                skip_ch.push_back(down[i].res[j].cout);
+            }
+            if (down[i].has_down) skip_ch.push_back(boc[i]);
+        }
+        dup(mid_res0, "mid_block.resnets.0", mid_res0.cin); dup(mid_res1, "mid_block.resnets.1", mid_res1.cin);
+        for (int i = 0; i < n_levels; ++i)
+            for (int j = 0; j < layers_per_block + 1; ++j) {
+                SDE_REQUIRE(!skip_ch.empty(), SDE_ERR_MODEL, "unet: skip stack underflow while planning shortcut weights");
+                const int sc = skip_ch.back(); skip_ch.pop_back();
+                dup(up[i].res[j], "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), up[i].res[j].cin - sc);
+            }
+    }
     // stable pointers now that the vectors are final
     for (auto& d : down) { for (auto& r : d.res) all_res.push_back(&r); for (auto& t : d.att) transformers.push_back(&t); }
     all_res.push_back(&mid_res0); transformers.push_back(&mid_att); all_res.push_back(&mid_res1);
@@ -411,39 +493,45 @@ void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, f
         for (int i = 0; i < n_transformers; ++i)
             linear(ex, transformers[i]->kv2, ehs_h, ctx_dim, N * S, kv_cache[i], 2 * transformers[i]->C);
     // 3. encoder
-    struct Skip { half_t* p; int C, H, W; };
+    struct Skip { Tn t; int C, H, W; };
     std::vector<Skip> skips;
     int H = h, W = w;
-    half_t* cur = ar.get<half_t>((size_t)N * H * W * boc[0]);
-    conv3x3(ex, conv_in, x_packed, kInPad, N, H, W, 1, 0, cur, boc[0], conv_in.bias, nullptr, 0);
+    auto trunk = [&](int Hx, int Wx, int Cx) {
+        Tn t;
+        t.hi = ar.get<half_t>((size_t)N * Hx * Wx * Cx);
+        if (ex.split(Hx * Wx)) t.lo = ar.get<half_t>((size_t)N * Hx * Wx * Cx);
+        return t;
+    };
+    Tn cur = trunk(H, W, boc[0]);
+    conv3x3(ex, conv_in, x_packed, kInPad, N, H, W, 1, 0, cur.hi, boc[0], conv_in.bias, nullptr, 0, EPI_STD, nullptr, 0, 0, nullptr, cur.lo);
     int C = boc[0];
     skips.push_back({cur, C, H, W});
     for (int i = 0; i < n_levels; ++i) {
         for (int j = 0; j < layers_per_block; ++j) {
-            cur = resnet(ex, down[i].res[j], cur, C, nullptr, 0, N, H, W, eps, tbias);
+            cur = resnet(ex, down[i].res[j], cur, C, Tn(), 0, N, H, W, eps, tbias);
             C = down[i].res[j].cout;
             if (!down[i].att.empty()) cur = transformer(ex, down[i].att[j], cur, N, H, W, kv_cache[down[i].att[j].kv_index], S);
             skips.push_back({cur, C, H, W});
         }
         if (down[i].has_down) {
             const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-            half_t* d = ar.get<half_t>((size_t)N * Ho * Wo * C);
-            conv3x3(ex, down[i].down, cur, C, N, H, W, 2, 0, d, C, down[i].down.bias, nullptr, 0);
+            Tn d = trunk(Ho, Wo, C);
+            conv3x3(ex, down[i].down, cur.hi, C, N, H, W, 2, 0, d.hi, C, down[i].down.bias, nullptr, 0, EPI_STD, nullptr, 0, 0, nullptr, d.lo);
             cur = d; H = Ho; W = Wo;
             skips.push_back({cur, C, H, W});
         }
     }
     // 4. middle
-    cur = resnet(ex, mid_res0, cur, C, nullptr, 0, N, H, W, eps, tbias);
+    cur = resnet(ex, mid_res0, cur, C, Tn(), 0, N, H, W, eps, tbias);
     cur = transformer(ex, mid_att, cur, N, H, W, kv_cache[mid_att.kv_index], S);
-    cur = resnet(ex, mid_res1, cur, C, nullptr, 0, N, H, W, eps, tbias);
+    cur = resnet(ex, mid_res1, cur, C, Tn(), 0, N, H, W, eps, tbias);
     // 5. decoder: cat([hidden, skip]) — hidden first
     for (int i = 0; i < n_levels; ++i) {
         for (int j = 0; j < layers_per_block + 1; ++j) {
             SDE_REQUIRE(!skips.empty(), SDE_ERR_MODEL, "unet: skip stack underflow");
             Skip s = skips.back(); skips.pop_back();
             SDE_REQUIRE(s.H == H && s.W == W, SDE_ERR_MODEL, "unet: skip connection size mismatch");
-            cur = resnet(ex, up[i].res[j], cur, C, s.p, s.C, N, H, W, eps, tbias);
+            cur = resnet(ex, up[i].res[j], cur, C, s.t, s.C, N, H, W, eps, tbias);
             C = up[i].res[j].cout;
             if (!up[i].att.empty()) cur = transformer(ex, up[i].att[j], cur, N, H, W, kv_cache[up[i].att[j].kv_index], S);
         }
@@ -453,14 +541,14 @@ void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, f
             // allows every image size divisible by 8 (impl_txt2img.rs:251-253).  Stride-2 convs round up, so that size is 2x or 2x - 1.
             SDE_REQUIRE(!skips.empty(), SDE_ERR_MODEL, "unet: skip stack underflow");
             const int Hu = skips.back().H, Wu = skips.back().W;
-            half_t* u = ar.get<half_t>((size_t)N * Hu * Wu * C);
-            conv3x3(ex, up[i].up, cur, C, N, H, W, 1, 1, u, C, up[i].up.bias, nullptr, 0, EPI_STD, nullptr, Hu, Wu);
+            Tn u = trunk(Hu, Wu, C);
+            conv3x3(ex, up[i].up, cur.hi, C, N, H, W, 1, 1, u.hi, C, up[i].up.bias, nullptr, 0, EPI_STD, nullptr, Hu, Wu, nullptr, u.lo);
             cur = u; H = Hu; W = Wu;
         }
     }
     // 6. head
     half_t* hn = ar.get<half_t>((size_t)N * H * W * C);
-    groupnorm(ex, norm_out, cur, C, nullptr, 0, N, H * W, eps, true, hn);
+    groupnorm(ex, norm_out, cur.hi, C, nullptr, 0, N, H * W, eps, true, hn, cur.lo);
     conv3x3(ex, conv_out, hn, C, N, H, W, 1, 0, nullptr, 0, conv_out.bias, nullptr, 0, EPI_NCHW_F32, out_nchw);
 }
 
@@ -518,7 +606,7 @@ void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, in
     int C = conv_in.N;
     half_t* cur = ar.get<half_t>((size_t)M0 * C);
     conv3x3(ex, conv_in, z, kInPad, B, H, W, 1, 0, cur, C, conv_in.bias, nullptr, 0);
-    cur = resnet(ex, mid_res0, cur, C, nullptr, 0, B, H, W, eps, nullptr);
+    cur = resnet(ex, mid_res0, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi;
     {   // AttentionBlock: single head over H*W tokens
         const int S = H * W, M = B * S;
         half_t* o = ar.get<half_t>((size_t)M * C);
@@ -570,9 +658,9 @@ void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, in
         ar.release(mk);
         cur = o;
     }
-    cur = resnet(ex, mid_res1, cur, C, nullptr, 0, B, H, W, eps, nullptr);
+    cur = resnet(ex, mid_res1, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi;
     for (int i = 0; i < n_levels; ++i) {
-        for (auto& r : up[i].res) { cur = resnet(ex, r, cur, C, nullptr, 0, B, H, W, eps, nullptr); C = r.cout; }
+        for (auto& r : up[i].res) { cur = resnet(ex, r, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi; C = r.cout; }
         if (up[i].has_up) {
             half_t* u = ar.get<half_t>((size_t)B * 4 * H * W * C);
             conv3x3(ex, up[i].up, cur, C, B, H, W, 1, 1, u, C, up[i].up.bias, nullptr, 0);

@@ -38,12 +38,19 @@ struct DevNorm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
 struct ResnetW {
     DevNorm n1, n2;
     DevLinear conv1, conv2, shortcut;
+    // UNet only: the shortcut weight laid out for split-fp16 operands, K = [x.hi | x.lo] against [W | W] (twice the K of a small
+    // 1x1 conv instead of rounding the trunk to fp16 on its way through every channel-changing resnet).  sc_c0 = channels of the
+    // first concat source (the hidden state); a concat input takes two chained GEMMs, one per source (shortcut_a2 then shortcut_b2).
+    DevLinear shortcut_a2, shortcut_b2;
+    int sc_c0 = 0;
+    bool has_sc2 = false;
     bool has_shortcut = false, has_temb = false;
     int cin = 0, cout = 0, temb_off = 0;
 };
 struct TransformerW {
     DevNorm gn, ln1, ln2, ln3;
     DevLinear proj_in, proj_out, qkv, out1, q2, kv2, out2, ff1, ff2;
+    DevLinear proj_out2;   // proj_out for a split-fp16 operand: K = [h.hi | h.lo] against [W | W]
     int C = 0, heads = 0, kv_index = 0;
 };
 struct VaeAttnW {
@@ -55,7 +62,11 @@ struct VaeAttnW {
 struct Exec {
     LaunchCtx ctx;
     Arena* arena = nullptr;
+    // UNet trunk (the tensor that runs resnet -> transformer -> resnet ..., the skip connections and the shortcut outputs) kept as
+    // split fp16 (hi + lo, kernels.h) wherever a level has at most split_max_hw pixels; 0 = plain fp16 everywhere (VAE decoder).
+    long long split_max_hw = 0;
     bool dry() const { return arena->dry; }
+    bool split(int HW) const { return split_max_hw > 0 && HW <= split_max_hw; }
 };
 
 struct WeightBuilder;  // model.cpp
@@ -122,6 +133,8 @@ struct WeightBuilder {
     // rows of `names` are concatenated along N; cin_pad pads the per-tap channel count
     DevLinear linear(const std::vector<std::string>& names, const std::vector<std::string>& bias_names, int cin_pad = 0,
                      bool geglu = false);
+    // 1x1 / Linear weight for a split-fp16 operand: input channels [i0, i0 + n) of `name` laid out twice along K ([W | W], K = 2n)
+    DevLinear linear_dup(const std::string& name, const std::vector<std::string>& bias_names, int i0, int n);
     DevNorm norm(const std::string& prefix);
     std::vector<float> host_f32(const std::string& name) const;
     float* upload_f32(const std::vector<float>& v);

@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* X0, const h
     }
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, int rows_per_block,
+// X0lo / X1lo: low parts of split-fp16 inputs (kernels.h), or null.  The statistics pass reads the high parts only (a 2^-11
+// relative perturbation per element moves a group's mean / variance by ~2^-11 / sqrt(count)); the normalised value uses hi + lo.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const half_t* X1, const half_t* X0lo, const half_t* X1lo, int C0, int C1, int HW, int rows_per_block,
                                                        const float* part, int nchunks, int groups, float eps, const float* gamma,
                                                        const float* beta, int silu, half_t* Y)
 {
@@ -142,7 +144,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const h
     const int total = (r1 - r0) * CX;
     // 4 octets per trip: all loads first, so 4 x 16 B per thread are in flight
     for (int i0 = tid; i0 < total; i0 += 4 * blockDim.x) {
-        half8 v[4];
+        half8 v[4], vl[4];
         int cc[4]; long long rw[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -150,8 +152,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const h
             const int rr = i / CX;
             cc[u] = (i - rr * CX) * 8;
             rw[u] = base_row + r0 + rr;
-            const half_t* src = cc[u] < C0 ? X0 + rw[u] * C0 + cc[u] : X1 + rw[u] * C1 + (cc[u] - C0);
-            v[u] = *(const half8*)src;
+            const bool first = cc[u] < C0;
+            const long long off = first ? rw[u] * C0 + cc[u] : rw[u] * C1 + (cc[u] - C0);
+            v[u] = *(const half8*)((first ? X0 : X1) + off);
+            const half_t* lo = first ? X0lo : X1lo;
+            if (lo) vl[u] = *(const half8*)(lo + off);
+            else
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vl[u][j] = (half_t)0.f;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -161,7 +169,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const h
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float4 t = abp[j];
-                    float y0 = (float)v[u][2 * j] * t.x + t.y, y1 = (float)v[u][2 * j + 1] * t.z + t.w;
+                    float y0 = ((float)v[u][2 * j] + (float)vl[u][2 * j]) * t.x + t.y, y1 = ((float)v[u][2 * j + 1] + (float)vl[u][2 * j + 1]) * t.z + t.w;
                     if (silu) { y0 = y0 / (1.0f + __expf(-y0)); y1 = y1 / (1.0f + __expf(-y1)); }
                     o[2 * j] = (half_t)y0; o[2 * j + 1] = (half_t)y1;
                 }
@@ -176,7 +184,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const h
 // Needs cpg % 4 == 0 (8-byte chunks never straddle a group or the concat boundary) and HW*cpg/4 <= 256*GN_SMALL_MAX.
 #define GN_SMALL_MAX 24
 typedef _Float16 half4n __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void gn_small_kernel(const half_t* X0, const half_t* X1, int C0, int C1, int HW, int groups, float eps,
+template <bool LO>
+__global__ __launch_bounds__(256) void gn_small_kernel(const half_t* X0, const half_t* X1, const half_t* X0lo, const half_t* X1lo, int C0, int C1, int HW, int groups, float eps,
                                                        const float* gamma, const float* beta, int silu, half_t* Y)
 {
     __shared__ float red[2][4];
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* X0, const h
     const int g = blockIdx.x, nb = blockIdx.y, tid = threadIdx.x;
     const int total = HW * cq;
     const int c_base = g * cpg;
-    half4n v[GN_SMALL_MAX];
+    half4n v[GN_SMALL_MAX], vl[LO ? GN_SMALL_MAX : 1];
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int u = 0; u < GN_SMALL_MAX; ++u) {
@@ -192,15 +201,21 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* X0, const h
         if (i < total) {
             const int px = i / cq, c = c_base + (i - px * cq) * 4;
             const long long row = (long long)nb * HW + px;
-            const half_t* src = c < C0 ? X0 + row * C0 + c : X1 + row * C1 + (c - C0);
-            v[u] = *(const half4n*)src;
+            const bool first = c < C0;
+            const long long off = first ? row * C0 + c : row * C1 + (c - C0);
+            v[u] = *(const half4n*)((first ? X0 : X1) + off);
+            if (LO) {
+                const half_t* lo = first ? X0lo : X1lo;
+                if (lo) vl[u] = *(const half4n*)(lo + off);
+                else vl[u] = half4n{(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+            }
         }
     }
 #pragma unroll
     for (int u = 0; u < GN_SMALL_MAX; ++u) {
         if (tid + u * 256 < total) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { const float f = (float)v[u][j]; s += f; q += f * f; }
+            for (int j = 0; j < 4; ++j) { const float f = LO ? (float)v[u][j] + (float)vl[u][j] : (float)v[u][j]; s += f; q += f * f; }
         }
     }
     s = wave_sum(s); q = wave_sum(q);
@@ -222,7 +237,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* X0, const h
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = rstd * gg[j];
-                float y = (float)v[u][j] * a + (bb[j] - mean * a);   // same scale/shift form as the two-pass path
+                const float xv = LO ? (float)v[u][j] + (float)vl[u][j] : (float)v[u][j];
+                float y = xv * a + (bb[j] - mean * a);   // same scale/shift form as the two-pass path
                 if (silu) y = y / (1.0f + __expf(-y));
                 o[j] = (half_t)y;
             }
@@ -270,8 +286,12 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
             static const bool shp = getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"));
             if (shp) snprintf(nm, sizeof(nm), "gn1 HW%d C%d", a.HW, C); else snprintf(nm, sizeof(nm), "%s", a.silu ? "groupnorm_silu_fused_small" : "groupnorm_fused_small");
             ProfScope ps(ctx, nm, 0, 2 * bytes);
-            hipLaunchKernelGGL(gn_small_kernel, dim3(a.groups, a.NB), dim3(256), 0, ctx.stream, a.X0, a.X1, a.C0, a.C1, a.HW, a.groups, a.eps,
-                               a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
+            if (a.X0lo || a.X1lo)
+                hipLaunchKernelGGL(gn_small_kernel<true>, dim3(a.groups, a.NB), dim3(256), 0, ctx.stream, a.X0, a.X1, a.X0lo, a.X1lo, a.C0, a.C1, a.HW,
+                                   a.groups, a.eps, a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
+            else
+                hipLaunchKernelGGL(gn_small_kernel<false>, dim3(a.groups, a.NB), dim3(256), 0, ctx.stream, a.X0, a.X1, a.X0lo, a.X1lo, a.C0, a.C1, a.HW,
+                                   a.groups, a.eps, a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
             HIP_CHECK(hipGetLastError());
             return;
         }
@@ -289,13 +309,13 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
 #undef GN_STATS
     }
     {
-        ProfScope ps(ctx, nm_a, 0, 2 * bytes);
+        ProfScope ps(ctx, nm_a, 0, 2 * bytes + (double)a.NB * a.HW * 2.0 * ((a.X0lo ? a.C0 : 0) + (a.X1lo ? a.C1 : 0)));
         // ~1024 blocks across the batch, at least 16 pixel rows each
         int bpi = std::max(1, std::min(cdiv(1024, a.NB), cdiv(a.HW, 16)));
         const int rpb = cdiv(a.HW, bpi);
         bpi = cdiv(a.HW, rpb);
         hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, a.NB), dim3(256), (size_t)(2 * C + 2 * a.groups) * sizeof(float), ctx.stream, a.X0, a.X1,
-                           a.C0, a.C1, a.HW, rpb, part, nchunks, a.groups, a.eps, a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
+                           a.X0lo, a.X1lo, a.C0, a.C1, a.HW, rpb, part, nchunks, a.groups, a.eps, a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -484,24 +504,29 @@ void launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* 
 }
 
 // y = half(S32 + A + B): the one rounding of a transformer block's residual stream, before proj_out reads it as an MFMA operand
-__global__ void sum_round_kernel(const float* S32, const half_t* A, const half_t* B, half_t* Y, long long n8)
+__global__ void sum_round_kernel(const float* S32, const half_t* A, const half_t* B, half_t* Y, half_t* Ylo, long long n8)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
         const float4 s0 = *(const float4*)(S32 + i * 8), s1 = *(const float4*)(S32 + i * 8 + 4);
         const half8 a = *(const half8*)(A + i * 8), b = *(const half8*)(B + i * 8);
         const float s[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        half8 o;
+        half8 o, l;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)(s[j] + (float)a[j] + (float)b[j]);
+        for (int j = 0; j < 8; ++j) {
+            const float x = s[j] + (float)a[j] + (float)b[j];
+            o[j] = (half_t)x;
+            l[j] = (half_t)(x - (float)o[j]);
+        }
         *(half8*)(Y + i * 8) = o;
+        if (Ylo) *(half8*)(Ylo + i * 8) = l;
     }
 }
-void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, int64_t n)
+void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, half_t* Ylo, int64_t n)
 {
     SDE_REQUIRE(n % 8 == 0 && S32 && A && B, SDE_ERR_INVALID_ARGUMENT, "sum_round: bad arguments");
-    ProfScope ps(ctx, "residual_sum_round", 0, 10.0 * n);
+    ProfScope ps(ctx, "residual_sum_round", 0, (Ylo ? 12.0 : 10.0) * n);
     hipLaunchKernelGGL(sum_round_kernel, dim3((unsigned)std::min<long long>(cdiv64(n / 8, 256), 8192)), dim3(256), 0, ctx.stream, S32, A, B, Y,
-                       (long long)(n / 8));
+                       Ylo, (long long)(n / 8));
     HIP_CHECK(hipGetLastError());
 }
 

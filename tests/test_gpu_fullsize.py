@@ -164,12 +164,15 @@ def _loop_at_config_batch(pipe, uw, ucfg, vw, vcfg, kind, B, S, D, h, w, steps, 
         ref = T.run(unet, S_.make(kind, **(oracle_kw or {})), sub, init[pick], steps, guidance, None, noise[:, pick])
         ref_img = unet_ref.decode_latents(vw, vcfg, torch.from_numpy(ref["final"])).numpy()
     assert res.unet_calls == len(ref["timesteps"])
-    for i in range(res.unet_calls):
-        for j, p in enumerate(pick):
-            err = rel_l2(res.noise_pred[i][p], ref["noise_pred"][i][j])
-            assert err < 1e-2, (kind, i, p, err)
+    errs = [(i, p, rel_l2(res.noise_pred[i][p], ref["noise_pred"][i][j])) for i in range(res.unet_calls) for j, p in enumerate(pick)]
+    quality = psnr(res.images[pick], ref_img)
+    if os.environ.get("SDE_PARITY_LOG"):     # measured margins for DESIGN.md
+        with open(os.environ["SDE_PARITY_LOG"], "a") as f:
+            f.write(f"{kind} B={B} S={S} {h}x{w}: " + " ".join(f"step{i}/sample{p}={e:.3e}" for i, p, e in errs) + f" psnr={quality:.1f}\n")
+    for i, p, err in errs:
+        assert err < 1e-2, (kind, i, p, err)
     assert np.isfinite(res.images).all()
-    assert psnr(res.images[pick], ref_img) >= 35.0, psnr(res.images[pick], ref_img)
+    assert quality >= 35.0, quality
 
 
 def test_config3_euler_a_batch8_two_steps(sd15):

@@ -49,7 +49,7 @@ def resnet(x, emb, w, p, groups, eps):
     h = Q(F.silu(U.group_norm(h, w, p + ".norm2", groups, eps)), "gn")
     h = U.conv(h, w, p + ".conv2")
     if (p + ".conv_shortcut.weight") in w:
-        x = Q(Q(U.conv(x, w, p + ".conv_shortcut", padding=0), "conv"), "c_short")
+        x = Q(Q(U.conv(Q(x, "op_short"), w, p + ".conv_shortcut", padding=0), "conv"), "c_short")
     return Q(Q(x + h, "resid"), "r_res")
 
 
@@ -70,9 +70,11 @@ def transformer(x, ctx, w, p, heads, groups, linear_proj, gelu="none"):
     B, C, H, W = x.shape
     r = x
     h = Q(U.group_norm(x, w, p + ".norm", groups, 1e-6), "gn")
-    assert not linear_proj
-    h = Q(Q(U.conv(h, w, p + ".proj_in", padding=0), "conv"), "c_y")
-    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    if not linear_proj:
+        h = Q(Q(U.conv(h, w, p + ".proj_in", padding=0), "conv"), "c_y")
+        h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    else:
+        h = Q(Q(U.linear(h.permute(0, 2, 3, 1).reshape(B, H * W, C), w, p + ".proj_in"), "conv"), "c_y")
     b = p + ".transformer_blocks.0"
     ln = lambda t, n: Q(F.layer_norm(t, (C,), w[f"{b}.{n}.weight"], w[f"{b}.{n}.bias"], 1e-5), "ln")
     n1 = ln(h, "norm1")
@@ -81,8 +83,10 @@ def transformer(x, ctx, w, p, heads, groups, linear_proj, gelu="none"):
     y = U.linear(ln(h, "norm3"), w, b + ".ff.net.0.proj")
     a, g = y.chunk(2, dim=-1)
     h = Q(Q(h + Q(Q(U.linear(Q(a * F.gelu(g), "geglu"), w, b + ".ff.net.2"), "conv"), "c_y"), "resid"), "r_final")
-    h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
-    h = U.conv(h, w, p + ".proj_out", padding=0)
+    if not linear_proj:
+        h = U.conv(h.reshape(B, H, W, C).permute(0, 3, 1, 2), w, p + ".proj_out", padding=0)
+    else:
+        h = U.linear(h, w, p + ".proj_out").reshape(B, H, W, C).permute(0, 3, 1, 2)
     return Q(Q(h + r, "resid"), "r_proj")
 
 
@@ -154,6 +158,8 @@ def forward(w, cfg, sample, t, ehs):
         orig_conv = U.conv
 
         def conv(x_, w_, p_, stride=1, padding=1):
+            if "samplers" in p_:
+                x_ = Q(x_, "op_samp")
             y = orig_conv(x_, w_, p_, stride, padding)
             return Q(Q(y, "conv"), "c_samp") if p_ in ("conv_in",) or "samplers" in p_ else y
         U.conv = conv
@@ -177,24 +183,31 @@ def main():
     ap.add_argument("--g", type=float, default=7.5)
     ap.add_argument("--scale", type=float, default=1.0, help="std of the sample fed to the UNet")
     ap.add_argument("--classes", default="all")
+    ap.add_argument("--sd21", action="store_true", help="SD v2.1 geometry at 96x96 (model dir /tmp/sde_cfg_sd21_f16)")
     args = ap.parse_args()
+    if args.sd21:
+        args.model_dir = os.environ.get("SDE_SD21_MODEL_DIR", "/tmp/sde_cfg_sd21_f16")
     if not os.path.exists(os.path.join(args.model_dir, ".complete")):
         from diffusers_amd import modelgen
-        modelgen.write_model_dir(args.model_dir, modelgen.unet_config(), modelgen.vae_config(), seed=42, dtype=np.float16)
+        modelgen.write_model_dir(args.model_dir, modelgen.sd21_unet_config() if args.sd21 else modelgen.unet_config(), modelgen.vae_config(), seed=42,
+                                 dtype=np.float16)
         open(os.path.join(args.model_dir, ".complete"), "w").write("ok")
     uw, cfg = md.load_unet(args.model_dir)
     uw = {k: torch.from_numpy(v) for k, v in uw.items()}
     rng = np.random.default_rng(16000 + args.S)
-    lat = torch.from_numpy((rng.standard_normal((1, 4, 64, 64)) * args.scale).astype(np.float32))
+    hw = 96 if args.sd21 else 64
+    lat = torch.from_numpy((rng.standard_normal((1, 4, hw, hw)) * args.scale).astype(np.float32))
     x = torch.cat([lat, lat], 0)
-    ehs = torch.from_numpy((rng.standard_normal((2, args.S, 768)) * 0.5).astype(np.float32))
+    ehs = torch.from_numpy((rng.standard_normal((2, args.S, 1024 if args.sd21 else 768)) * 0.5).astype(np.float32))
     all_cls = ["in", "gn", "ln", "conv", "resid", "stream", "attn_p", "attn_o", "geglu"]
     if args.classes == "all":
         runs = [[c] for c in all_cls] + [[c for c in all_cls if c != "stream"], all_cls]
     elif args.classes == "fine":
         runs = [[c] for c in ["c_conv1", "c_short", "c_qkv", "c_y", "c_samp", "r_res", "r_final", "r_proj"]]
     else:
-        runs = [c.split(",") for c in args.classes.split(";")]
+        CUR = "in,gn,ln,c_conv1,c_qkv,c_y,r_final,attn_p,attn_o,geglu,op_short,op_samp"   # the engine with its split-fp16 trunk
+        runs = [[x for x in c.replace("CUR", CUR).split(",") if not x.startswith("-")] for c in args.classes.split(";")]
+        runs = [[x for x in r if ("-" + x) not in c.split(",")] for r, c in zip(runs, args.classes.split(";"))]
     with torch.no_grad():
         ON.clear()
         t0 = time.time()
