@@ -6,7 +6,13 @@ DPM-Solver++ 30 steps, CFG 7.5 (UNet batch 16), fp16, followed by the batched VA
 Weights are random-init (no checkpoints exist offline), written once as a pyke model directory and loaded through the
 product's own ONNX loader.  Text embeddings, initial latents and the image output buffer are resident in HBM before
 the timed region.  With --gpus N every rank runs the same workload on its own GPU (independent prompts: no data-path
-collective), value = all images / max-over-ranks time.
+collective), value = all images / max-over-ranks time ("scaling": "weak").
+
+Launching: under torchrun (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) each process finds
+RANK / LOCAL_RANK / WORLD_SIZE in its environment.  Started plainly as `python bench.py --gpus N` (no WORLD_SIZE), this
+process starts the N ranks itself -- one fresh child per GPU, before anything here has touched the GPU -- and prints rank 0's
+line.  `--prompts P` switches to BASELINE configs[2]: P prompts with per-prompt seeds, sharded contiguously over the ranks and
+run in micro-batches of --batch ("scaling": "strong", a step = one pass over all P prompts).
 """
 import argparse
 import ctypes as C
@@ -40,39 +46,57 @@ def ensure_model_dir(path, rank, world, barrier):
     return path
 
 
-def cpu_baseline(model_dir, seconds_budget=30.0):
-    """Oracle (torch CPU fp32 restatement of the reference's ORT graphs) on config[0]: B=1, CFG (UNet batch 2),
-    Euler 20 steps, 512x512, fp32.  Bounded sample: UNet forwards until ~budget, + one VAE decode; extrapolated."""
-    from oracle import model_dir as md, unet_ref
+def cpu_baseline(model_dir, seconds_budget=60.0):
+    """Oracle (torch CPU fp32 restatement of the reference's loop and of its two ORT graphs) on configs[0]: B=1, CFG 7.5 (UNet batch 2),
+    Euler 20 steps, 512x512, fp32, + the VAE decode -- the REAL loop (oracle/txt2img.py), timed end to end.  If one UNet call is so
+    slow that 20 of them would not fit the budget, a bounded sample is timed and extrapolated instead, and the line says so."""
+    from oracle import model_dir as md, schedulers as OS, txt2img as OT, unet_ref
     cores = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)))
     torch.set_num_threads(cores)
     uw, ucfg = md.load_unet(model_dir)
     uw = {k: torch.from_numpy(v) for k, v in uw.items()}
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, 64, 64, generator=g) * 14.6
-    ehs = torch.randn(2, 77, 768, generator=g) * 0.5
+    vw, vcfg = md.load_vae_decoder(model_dir)
+    vw = {k: torch.from_numpy(v) for k, v in vw.items()}
+    rng = np.random.default_rng(0)
+    init = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
+    ehs = (np.random.default_rng(1).standard_normal((2, 77, 768)) * 0.5).astype(np.float32)
+    calls = []
+
+    def unet(x, t, e):
+        t0 = time.time()
+        y = unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), t, torch.from_numpy(e)).numpy()
+        calls.append(time.time() - t0)
+        return y
+
     with torch.no_grad():
         t0 = time.time()
-        unet_ref.unet_forward(uw, ucfg, x, 999.0, ehs)   # warm-up
+        unet(np.concatenate([init, init]) * 14.6, 999.0, ehs)     # warm-up (thread pool, allocator)
         warm = time.time() - t0
-        n, t_un = 0, 0.0
-        while n < 2 or (t_un + warm < seconds_budget * 0.6 and n < 4):
+        calls.clear()
+        if warm * 21 <= seconds_budget * 1.5:
             t0 = time.time()
-            unet_ref.unet_forward(uw, ucfg, x, 946.0, ehs)
-            t_un += time.time() - t0
+            ref = OT.run(unet, OS.make("euler"), ehs, init, 20, 7.5)
+            img = unet_ref.decode_latents(vw, vcfg, torch.from_numpy(ref["final"]))
+            total = time.time() - t0
+            assert torch.isfinite(img).all()
+            t_unet = sum(calls) / len(calls)
+            return {"value": 1.0 / total, "unit": "images/sec", "cores": cores, "kind": "port",
+                    "sample": f"the whole configs[0] job, not a sample: 1 image, Euler 20 steps (20 UNet calls at batch 2, fp32, 64x64 latent, S=77) + "
+                              f"VAE decode of the 512x512 image, {total:.1f} s wall; torch CPU oracle (ORT is not installed)",
+                    "s_per_image": total, "unet_s_per_call": t_unet, "unet_it_per_s": 1.0 / t_unet}
+        n = 0
+        while n < 2 or (sum(calls) + warm < seconds_budget * 0.6 and n < 4):
+            unet(np.concatenate([init, init]), 946.0, ehs)
             n += 1
-        t_unet = t_un / n
-        del uw
-        vw, vcfg = md.load_vae_decoder(model_dir)
-        vw = {k: torch.from_numpy(v) for k, v in vw.items()}
+        t_unet = sum(calls) / len(calls)
         t0 = time.time()
-        unet_ref.decode_latents(vw, vcfg, torch.randn(1, 4, 64, 64, generator=g) * 0.18215)
+        unet_ref.decode_latents(vw, vcfg, torch.from_numpy(init * 0.18215))
         t_vae = time.time() - t0
     s_per_image = 20 * t_unet + t_vae
     return {"value": 1.0 / s_per_image, "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} timed UNet forwards (batch 2, fp32, 64x64 latent, S=77) + 1 VAE decode of one 512x512 image, "
-                      f"extrapolated to Euler 20 steps (configs[0]); torch CPU oracle, ORT unavailable",
-            "unet_s_per_call": t_unet, "vae_s_per_image": t_vae, "unet_it_per_s": 1.0 / t_unet}
+            "sample": f"{n} timed UNet forwards (batch 2, fp32, 64x64 latent, S=77) + 1 VAE decode of one 512x512 image, EXTRAPOLATED to Euler 20 "
+                      f"steps (configs[0]) because the full loop would exceed the time budget on {cores} cores; torch CPU oracle (ORT is not installed)",
+            "s_per_image": s_per_image, "unet_s_per_call": t_unet, "unet_it_per_s": 1.0 / t_unet}
 
 
 # engine profiler class -> HIP kernel symbol(s) in a rocprofv3 kernel trace
@@ -87,6 +111,31 @@ ROCPROF_SYMBOL = {
 }
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as children and relay rank 0's JSON line.
+    Runs before this process has initialised the GPU (children are fresh interpreters, not forks of a GPU process)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
+    if lines:
+        print(lines[-1])
+    rc = max(abs(c) for c in codes)
+    if rc or not lines:
+        print(f"[bench] rank exit codes {codes}", file=sys.stderr)
+    sys.exit(rc if rc else (0 if lines else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -97,11 +146,19 @@ def main():
     ap.add_argument("--scheduler", default="dpmpp")
     ap.add_argument("--model-dir", default=os.environ.get("SDE_BENCH_MODEL_DIR", "/tmp/sde_bench_sd15_f16"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=25.0)
+    ap.add_argument("--cpu-budget", type=float, default=60.0)
     ap.add_argument("--cfg-pair-split", action="store_true",
                     help="BASELINE config 3 variant: ranks (2p, 2p+1) share 2*batch prompts; each runs one CFG half of every UNet "
                          "call (UNet batch stays 2*batch per GPU) and they all-gather the halves over RCCL once per step")
+    ap.add_argument("--prompts", type=int, default=0,
+                    help="BASELINE configs[2]: this many prompts (seeds 0..P-1) sharded over the ranks, micro-batches of --batch, strong scaling")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launch / rendezvous / aggregation rehearsal on a box without GPUs: gloo, and a sleep stands in for the engine "
+                         "(the line says so in `data`; it is not a measurement)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus, sys.argv[1:])      # does not return
 
     if os.environ.get("SDE_BENCH_DEBUG"):      # dump every thread's Python stack if the run stalls
         import faulthandler
@@ -113,72 +170,160 @@ def main():
     if world > 1:
         import torch.distributed as dist
         # SDE_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then share devices)
-        backend = os.environ.get("SDE_BENCH_BACKEND", "nccl")
-        local_rank %= max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local_rank)
+        backend = "gloo" if args.rehearse else os.environ.get("SDE_BENCH_BACKEND", "nccl")
+        if not args.rehearse:
+            local_rank %= max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if args.rehearse else torch.device("cuda", local_rank)
+    if not args.rehearse:
+        torch.cuda.set_device(dev)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    model_dir = ensure_model_dir(args.model_dir, rank, world, barrier)
+    def sync():
+        if not args.rehearse:
+            torch.cuda.synchronize()
 
-    from diffusers_amd import schedulers as N
-    from diffusers_amd.pipeline import StableDiffusionOptions, StableDiffusionPipeline, StableDiffusionTxt2ImgOptions
-
-    t0 = time.time()
-    pipe = StableDiffusionPipeline(model_dir, StableDiffusionOptions(device_id=local_rank))
-    load_s = time.time() - t0
     B, S, D, H, W = args.batch, 77, 768, 512, 512
     pair = None
+    n_groups, group_idx = world, rank              # prompt shards: one per rank, or one per CFG pair
     if args.cfg_pair_split:
         from diffusers_amd.sharding import CfgPair, pair_layout
         assert dist is not None, "--cfg-pair-split needs an even number of ranks >= 2"
-        pidx, half, n_pairs = pair_layout(world, rank)
-        groups = [dist.new_group([2 * p, 2 * p + 1]) for p in range(n_pairs)]
-        pair = CfgPair(dist, groups[pidx], half, dev)
-        B = 2 * B                                      # prompts per PAIR; each GPU still runs a UNet batch of 2*args.batch
-    g = torch.Generator(device="cpu").manual_seed(1 + (rank // 2 if pair else rank))   # identical inputs inside a pair
-    ehs = (torch.randn(2 * B, S, D, generator=g) * 0.5).to(dev)
-    init = torch.randn(B, 4, H // 8, W // 8, generator=g).to(dev)
-    images = torch.empty(B, H, W, 3, device=dev, dtype=torch.float32)
-    ptrs = dict(ehs=ehs.data_ptr(), S=S, D=D, init_latents=init.data_ptr(), images=images.data_ptr())
-    opts = StableDiffusionTxt2ImgOptions(height=H, width=W, guidance_scale=7.5, steps=args.denoise_steps, batch_size=B, seed=0)
+        group_idx, half, n_groups = pair_layout(world, rank)
+        groups = [dist.new_group([2 * p, 2 * p + 1]) for p in range(n_groups)]
+        pair = CfgPair(dist, groups[group_idx], half, dev)
+        if not args.prompts:
+            B = 2 * B                                  # prompts per PAIR; each GPU still runs a UNet batch of 2*args.batch
 
-    def one_step():
+    load_s = 0.0
+    pipe = None
+    if not args.rehearse:
+        model_dir = ensure_model_dir(args.model_dir, rank, world, barrier)
+        from diffusers_amd import schedulers as N
+        from diffusers_amd.pipeline import StableDiffusionOptions, StableDiffusionPipeline, StableDiffusionTxt2ImgOptions
+        t0 = time.time()
+        pipe = StableDiffusionPipeline(model_dir, StableDiffusionOptions(device_id=local_rank))
+        load_s = time.time() - t0
+
+    class Acc:
+        unet_ms = vae_ms = enq_ms = 0.0
+        calls = 0
+    acc = Acc()
+
+    def run_batch(ehs, init, images, noise, nb):
+        """one StableDiffusionTxt2ImgOptions::run over nb prompts whose inputs are resident in HBM"""
         sch = N.BY_NAME[args.scheduler].stable_diffusion_v1_optimized_default()
-        return opts.run(pipe, sch, device_ptrs=ptrs, cfg_pair=pair)
+        ptrs = dict(ehs=ehs.data_ptr(), S=S, D=D, init_latents=init.data_ptr(), images=images.data_ptr())
+        if noise is not None:
+            ptrs.update(step_noise=noise.data_ptr(), step_noise_rows=noise.shape[0])
+        o = StableDiffusionTxt2ImgOptions(height=H, width=W, guidance_scale=7.5, steps=args.denoise_steps, batch_size=nb, seed=0)
+        r = o.run(pipe, sch, device_ptrs=ptrs, cfg_pair=pair)
+        acc.unet_ms += r.unet_ms; acc.vae_ms += r.vae_ms; acc.calls += r.unet_calls; acc.enq_ms += r.host_enqueue_ms
+        return r
+
+    check = []                                          # image tensors this rank decodes (finiteness check after the timed region)
+    if args.rehearse:
+        units_per_step = B if not args.prompts else None
+
+        def one_step():
+            time.sleep(0.02 * (1 + rank))
+            return None
+        if args.prompts:
+            from diffusers_amd.sharding import shard_range
+            b0, e0 = shard_range(args.prompts, n_groups, group_idx)
+            units_per_step = e0 - b0
+    elif not args.prompts:
+        # weak scaling (configs[1]): every rank runs B prompts of its own
+        g = torch.Generator(device="cpu").manual_seed(1 + group_idx)          # identical inputs inside a pair
+        ehs = (torch.randn(2 * B, S, D, generator=g) * 0.5).to(dev)
+        init = torch.randn(B, 4, H // 8, W // 8, generator=g).to(dev)
+        images = torch.empty(B, H, W, 3, device=dev, dtype=torch.float32)
+        check.append(images if pair is None else (images[:(B + 1) // 2] if pair.half == 0 else images[(B + 1) // 2:]))
+        units_per_step = B
+
+        def one_step():
+            return run_batch(ehs, init, images, None, B)
+    else:
+        # strong scaling (configs[2]): P prompts in all; this rank's (pair's) contiguous shard in micro-batches of args.batch.  Every
+        # prompt brings its own embeddings and its own seed (latents from StdRng(seed), scheduler noise from StdRng(seed + 31337), as one
+        # reference run per prompt would draw them), so the images do not depend on the number of GPUs or on the micro-batching.
+        import ctypes as C
+        from diffusers_amd import _lib
+        from diffusers_amd.sharding import prompt_seed, shard_range
+        b0, e0 = shard_range(args.prompts, n_groups, group_idx)
+        units_per_step = e0 - b0
+        h8, w8 = H // 8, W // 8
+        per1 = 4 * h8 * w8
+        sch0 = N.BY_NAME[args.scheduler].stable_diffusion_v1_optimized_default()
+        sch0.set_timesteps(args.denoise_steps)
+        nt = len(sch0.timesteps())
+        needs_noise = args.scheduler in ("euler_a", "ddpm")
+
+        def draws(seed, skip, n):
+            out = np.empty(n, np.float32)
+            _lib.check(_lib.lib().sde_rng_standard_normal(C.c_uint64(seed), C.c_uint64(skip), out.ctypes.data, n))
+            return out
+
+        batches = []
+        for m0 in range(b0, e0, args.batch):
+            idx = list(range(m0, min(e0, m0 + args.batch)))
+            nb = len(idx)
+            un, tx, ini, nz = [], [], [], []
+            for pidx in idx:
+                g = torch.Generator(device="cpu").manual_seed(10_000 + pidx)
+                e2 = torch.randn(2, S, D, generator=g) * 0.5
+                un.append(e2[0]); tx.append(e2[1])
+                seed = prompt_seed(0, pidx)
+                ini.append(torch.from_numpy(draws(seed, 0, per1)).view(4, h8, w8))
+                if needs_noise:
+                    nz.append(torch.from_numpy(draws((seed + 31337) & 0xFFFFFFFFFFFFFFFF, 0, nt * per1)).view(nt, 4, h8, w8))
+            ehs_b = torch.stack(un + tx).to(dev)
+            init_b = torch.stack(ini).to(dev)
+            noise_b = torch.stack(nz, dim=1).contiguous().to(dev) if needs_noise else None      # [nt, nb, 4, h, w]
+            img_b = torch.empty(nb, H, W, 3, device=dev, dtype=torch.float32)
+            batches.append((ehs_b, init_b, img_b, noise_b, nb))
+            check.append(img_b if pair is None else (img_b[:(nb + 1) // 2] if pair.half == 0 else img_b[(nb + 1) // 2:]))
+
+        def one_step():
+            r = None
+            for bt in batches:
+                r = run_batch(*bt)
+            return r
 
     for _ in range(args.warmup):
         one_step()
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+    acc.unet_ms = acc.vae_ms = acc.enq_ms = 0.0; acc.calls = 0
+    sync(); barrier(); sync()
     t0 = time.perf_counter()
-    unet_ms = vae_ms = enq_ms = 0.0
-    calls = 0
     for _ in range(args.steps):
-        r = one_step()
-        unet_ms += r.unet_ms; vae_ms += r.vae_ms; calls += r.unet_calls; enq_ms += r.host_enqueue_ms
-    torch.cuda.synchronize(); barrier(); torch.cuda.synchronize()
+        one_step()
+    sync(); barrier(); sync()
     elapsed = time.perf_counter() - t0
+    unet_ms, vae_ms, enq_ms, calls = acc.unet_ms, acc.vae_ms, acc.enq_ms, acc.calls
+    units = float(units_per_step * args.steps) if (pair is None or pair.half == 0) else 0.0   # a pair's images are counted once
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        on = dev if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([elapsed], device=on, dtype=torch.float64)
+        u = torch.tensor([units], device=on, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    mine = images if pair is None else (images[:(B + 1) // 2] if pair.half == 0 else images[(B + 1) // 2:])
-    assert torch.isfinite(mine).all(), "non-finite pixels in the decoded images"
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        elapsed, units = float(t.item()), float(u.item())
+    for im in check:
+        assert torch.isfinite(im).all(), "non-finite pixels in the decoded images"
 
     # per-kernel timing: same workload once more with HIP events around every launch (on the engine's stream)
     roof = None
     kernel_table = []
-    if pair is not None and rank != 0:
+    if pair is not None and rank != 0 and not args.rehearse:
         one_step()                      # the pair's peer (and every other pair, to keep ranks aligned) takes part in the profiled pass
-    if rank == 0:
+    if rank == 0 and not args.rehearse:
         pipe.profile_reset(); pipe.profile(True)
         rp = one_step()
         stats = pipe.profile_get()
@@ -215,16 +360,22 @@ def main():
                     "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "launches": dom["launches"],
                     "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2)}
 
-    total_images = (world // 2 if pair else world) * B * args.steps
-    value = total_images / elapsed
+    value = units / elapsed
+    strong = args.prompts > 0
+    if strong:
+        workload = (f"SD v1.5 geometry 512x512, {args.scheduler} {args.denoise_steps} steps, CFG 7.5, {args.prompts} prompts (seeds 0..{args.prompts - 1}) "
+                    f"sharded over {n_groups} {'GPU pairs' if pair else 'GPUs'} in micro-batches of {args.batch}, fp16, + VAE decode; random-init weights, text length 77")
+    else:
+        workload = (f"SD v1.5 geometry 512x512, {args.scheduler} {args.denoise_steps} steps, CFG 7.5, batch {args.batch} per GPU "
+                    f"(UNet batch {2 * args.batch}), fp16, + batched VAE decode; random-init weights, text length 77")
     per_image_tflop = (2 * args.denoise_steps * UNET_GFLOP_PER_SAMPLE + VAE_GFLOP_PER_IMAGE) / 1e3
     out = {
         "metric": "images/sec (SD1.5 512x512, 30 steps, fp16)", "value": round(value, 4), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-        "config": {"workload": f"SD v1.5 geometry 512x512, {args.scheduler} {args.denoise_steps} steps, CFG 7.5, batch {args.batch} per GPU "
-                               f"(UNet batch {2 * args.batch}), fp16, + batched VAE decode; random-init weights, text length 77",
-                   "global_batch": (world // 2 if pair else world) * B,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f16",
+        "data": "rehearsal: a sleep stands in for the engine, NOT a measurement" if args.rehearse else "synthetic",
+        "config": {"workload": workload,
+                   "global_batch": args.prompts if strong else n_groups * B,
                    "parallelism": (f"dp{world // 2} x cfg-pair2 (uncond/text halves on paired GPUs, 2-rank RCCL all-gather of [B,4,h,w] per step)"
                                    if pair else f"dp{world} (independent prompts, no collective)"),
                    "unet_calls_per_step": calls // max(1, args.steps), "reference_quirks": True},
@@ -236,8 +387,9 @@ def main():
         "model_load_s": round(load_s, 1),
         "roofline": roof, "kernels": kernel_table,
     }
-    pipe.close()
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if pipe is not None:
+        pipe.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.rehearse:
         try:
             out["cpu_baseline"] = cpu_baseline(model_dir, args.cpu_budget)
         except Exception as e:  # the baseline is a reported side figure; never lose the GPU line over it
