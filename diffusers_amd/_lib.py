@@ -79,6 +79,7 @@ SYMBOLS = {
     "sde_vae_decode_dev": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sde_vae_decoder_run": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sde_approximate_decode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sde_approximate_decode_noalloc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sde_sched_cfg_sd_v1": (None, [_i, C.POINTER(SchedCfg)]),
     "sde_sched_cfg_default": (None, [_i, C.POINTER(SchedCfg)]),
     "sde_scheduler_create": (_i, [_i, C.POINTER(SchedCfg), C.POINTER(_vp)]),

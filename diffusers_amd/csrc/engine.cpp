@@ -284,6 +284,33 @@ static void decode_on_lane(sde_engine* e, PreviewLane& L, const float* d_latents
     }
 }
 
+// ------------------------------------------------------------------------------------------ static scratch (no-allocation entry point)
+// Staging memory of sde_approximate_decode_noalloc: a file-scope device array, so the call needs no hipMalloc.  Every GPU this
+// library runs on holds its own copy (SDE_NOALLOC_SCRATCH_BYTES, until the process ends) at its own address; in host code the
+// array's NAME is only a handle for hipGetSymbolAddress -- it is never passed to a kernel or a copy.  The per-device address is
+// looked up once, with that device current, and kept in g_scratch_ptr.
+static __device__ __align__(256) unsigned char g_noalloc_scratch[SDE_NOALLOC_SCRATCH_BYTES];
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;                       // guards the table below
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+std::mutex g_scratch_use_mu[kMaxDevices];      // one user of a device's array at a time inside this process
+
+// `device` must be the current device
+void* noalloc_scratch_for(int device)
+{
+    SDE_REQUIRE(device >= 0 && device < kMaxDevices, SDE_ERR_DEVICE, "device ordinal beyond the static scratch table");
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        HIP_CHECK(hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch)));
+        SDE_REQUIRE(p != nullptr, SDE_ERR_DEVICE, "hipGetSymbolAddress returned a null address for the static scratch array");
+        g_scratch_ptr[device] = p;
+    }
+    return g_scratch_ptr[device];
+}
+}  // namespace
+
 // ------------------------------------------------------------------------------------------ C ABI: library / engine
 extern "C" {
 
@@ -322,6 +349,7 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
         SDE_REQUIRE(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, SDE_ERR_DEVICE,
                     std::string("kernels are built for gfx950 only; device is ") + prop.gcnArchName);
         HIP_CHECK(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        (void)noalloc_scratch_for(e->device);   // resolve this device's static scratch address at set-up (sde_approximate_decode_noalloc)
         e->prof.stream = e->stream;
         e->zeros.ensure(4096, true, e->stream);
         e->ctx.stream = e->stream; e->ctx.prof = &e->prof; e->ctx.zeros = e->zeros.as<half_t>(); e->ctx.force_naive = o.force_naive != 0;
@@ -495,6 +523,30 @@ sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, in
         launch_approx_decode(e->ctx, e->latents.as<float>(), e->images.as<float>(), B, h, w);
         HIP_CHECK(hipStreamSynchronize(e->stream));
         HIP_CHECK(hipMemcpy(images, e->images.p, no * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+sde_status sde_approximate_decode_noalloc(sde_engine* e, const float* latents, int B, int h, int w, float* images)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && latents && images && B > 0 && h > 0 && w > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
+        const size_t nl = (size_t)B * 4 * h * w, no = (size_t)B * h * w * 3;
+        const size_t off_out = (nl * 4 + 255) & ~(size_t)255;
+        SDE_REQUIRE(off_out + no * 4 <= (size_t)SDE_NOALLOC_SCRATCH_BYTES, SDE_ERR_INVALID_ARGUMENT,
+                    "sde_approximate_decode_noalloc: B*h*w = " + std::to_string((size_t)B * h * w) + " pixels need " +
+                        std::to_string(off_out + no * 4) + " bytes of staging, the static scratch holds " +
+                        std::to_string((size_t)SDE_NOALLOC_SCRATCH_BYTES) + " (use sde_approximate_decode)");
+        EngineLock lk(e);
+        engine_activate(e);
+        std::lock_guard<std::mutex> use(g_scratch_use_mu[e->device]);   // other engines on this GPU share the array
+        unsigned char* base = (unsigned char*)noalloc_scratch_for(e->device);
+        float* d_lat = (float*)base;
+        float* d_img = (float*)(base + off_out);
+        // nothing has to start at zero: the kernel reads [0, nl) of what this call uploads and writes all of [0, no)
+        HIP_CHECK(hipMemcpyAsync(d_lat, latents, nl * 4, hipMemcpyHostToDevice, e->stream));
+        launch_approx_decode(e->ctx, d_lat, d_img, B, h, w);
+        HIP_CHECK(hipMemcpyAsync(images, d_img, no * 4, hipMemcpyDeviceToHost, e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));
     });
 }
 

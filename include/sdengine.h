@@ -94,6 +94,15 @@ sde_status sde_vae_decoder_run(sde_engine* e, const float* latent_sample, int B,
 /* `approximate_decode_latents` (impl_main.rs:385-395): 4->3 channel linear map + clamp -> f32 [B,h,w,3]. */
 sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images_nhwc);
 
+/* The same as sde_approximate_decode for callers that cannot allocate device memory (code between hipStreamBeginCapture and
+ * EndCapture, tight serving loops, harnesses that forbid hipMalloc): it has NO counterpart in the reference.  It calls no
+ * hipMalloc / hipFree: the two staging tensors live in a static device array of SDE_NOALLOC_SCRATCH_BYTES that every GPU the
+ * library runs on holds until the process ends.  B*h*w pixels need 256-aligned(16*B*h*w) + 12*B*h*w bytes; a larger request is
+ * refused with SDE_ERR_INVALID_ARGUMENT (use sde_approximate_decode).  All calls on one GPU share that GPU's array: calls from
+ * this process are serialised on it, calls that overlap in any other way (e.g. a copy of the library loaded twice) would race. */
+#define SDE_NOALLOC_SCRATCH_BYTES (8u << 20)
+sde_status sde_approximate_decode_noalloc(sde_engine* e, const float* latents, int B, int h, int w, float* images_nhwc);
+
 /* Schedulers (trait DiffusionScheduler, schedulers/mod.rs:154-192) -------------------------- */
 typedef enum sde_scheduler_kind {
     SDE_SCHED_EULER = 0,   /* euler_discrete.rs */
