@@ -71,8 +71,16 @@ void launch_f16_to_f32(const LaunchCtx& ctx, const half_t* x, float* y, int64_t 
 
 // ------------------------------------------------------------------------------------------ time embedding
 // Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): emb = t * exp(-ln(10000) * k / (dim/2)); [cos | sin]
-__global__ void timestep_embedding_kernel(float t, float* out, int dim)
+__global__ void set_scalar_kernel(float* dst, float v) { if (threadIdx.x == 0) *dst = v; }
+void launch_set_scalar(const LaunchCtx& ctx, float* dst, float value)
 {
+    hipLaunchKernelGGL(set_scalar_kernel, dim3(1), dim3(64), 0, ctx.stream, dst, value);
+    HIP_CHECK(hipGetLastError());
+}
+
+__global__ void timestep_embedding_kernel(const float* t_dev, float* out, int dim)
+{
+    const float t = *t_dev;
     int half_dim = dim / 2;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= half_dim) return;
@@ -81,10 +89,10 @@ __global__ void timestep_embedding_kernel(float t, float* out, int dim)
     out[k] = cosf(a);
     out[half_dim + k] = sinf(a);
 }
-void launch_timestep_embedding(const LaunchCtx& ctx, float t, float* out, int dim)
+void launch_timestep_embedding(const LaunchCtx& ctx, const float* t_dev, float* out, int dim)
 {
     ProfScope ps(ctx, "timestep_embedding", 0, 4.0 * dim);
-    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(dim / 2, 64)), dim3(64), 0, ctx.stream, t, out, dim);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(dim / 2, 64)), dim3(64), 0, ctx.stream, t_dev, out, dim);
     HIP_CHECK(hipGetLastError());
 }
 

@@ -103,6 +103,21 @@ struct PinnedBuf {
     ~PinnedBuf() { if (p) (void)hipHostFree(p); }
 };
 
+// A UNet call (fill_kv = false) captured into a hipGraph: ~440 launches become one hipGraphLaunch.  Valid for one shape and one set
+// of buffer addresses; the timestep is not baked in (it is read from e->t_dev).
+struct UnetGraph {
+    long long key = -1;
+    const void* ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // x_packed, ehs, out, arena base, kv base, t_dev
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    void reset()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr; key = -1;
+    }
+};
+
 // A second stream with everything a VAE decode needs for itself (arena, split-K workspace, staging), so that preview
 // callbacks (StableDiffusionCallback::{Latents, Decoded, ApproximateDecoded}, mod.rs:41-86) run beside the denoise stream
 // instead of stalling it.  Created on first use.
@@ -138,6 +153,9 @@ struct sde_engine {
     DevBuf arena_buf, zeros, splitk_ws, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps, rescale_ws;
     PinnedBuf noise_host;
     std::unique_ptr<PreviewLane> preview;
+    DevBuf t_dev;                      // the UNet call's (truncated) timestep, read by the time-embedding kernel
+    std::vector<UnetGraph> graphs;     // captured UNet calls (unet_run)
+    bool use_graphs = true;            // SDE_GRAPH=0: launch by launch
     long long split_max_hw = 1LL << 40;   // UNet trunk as split fp16 at every level (Exec::split); SDE_SPLIT_MAX_HW: tuning hook (0 = off)
     std::vector<half_t*> kv_ptrs;
     std::mutex mu;  // one forward at a time per engine (reference: Session is Send+Sync; here calls serialize)
@@ -149,7 +167,9 @@ struct sde_engine {
     ~sde_engine()
     {
         (void)hipSetDevice(device);
-        if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+        if (stream) (void)hipStreamSynchronize(stream);
+        for (auto& g : graphs) g.reset();
+        if (stream) (void)hipStreamDestroy(stream);
     }
 };
 
@@ -201,13 +221,47 @@ static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w,
         Arena dry; dry.dry = true;
         Exec dx{e->ctx, &dry, e->split_max_hw};
         std::vector<half_t*> fake((size_t)e->unet.n_transformers, (half_t*)nullptr);
-        e->unet.forward(dx, nullptr, N, h, w, t, nullptr, S, fake.data(), true, nullptr);
+        e->unet.forward(dx, nullptr, N, h, w, nullptr, nullptr, S, fake.data(), true, nullptr);
         e->unet_peak = dry.peak; e->unet_key = key;
     }
     ensure_arena(e, std::max(e->unet_peak, e->vae_peak));
-    e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false;
-    Exec ex{e->ctx, &e->arena, e->split_max_hw};
-    e->unet.forward(ex, x_packed, N, h, w, t, ehs_h, S, e->kv_ptrs.data(), fill_kv, out);
+    e->t_dev.ensure(256);
+    // the exported graph casts the timestep to int64 (sd2pyke.py:121): truncation
+    launch_set_scalar(e->ctx, e->t_dev.as<float>(), truncf(t));
+    auto run_plain = [&] {
+        e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false;
+        Exec ex{e->ctx, &e->arena, e->split_max_hw};
+        e->unet.forward(ex, x_packed, N, h, w, e->t_dev.as<float>(), ehs_h, S, e->kv_ptrs.data(), fill_kv, out);
+    };
+    // the first call of a run (fill_kv) and profiled passes (events between the launches) go out launch by launch
+    if (!e->use_graphs || fill_kv || e->prof.enabled) { run_plain(); return; }
+    const void* ptrs[6] = {x_packed, ehs_h, out, e->arena_buf.p, e->kvbuf.p, e->t_dev.p};
+    UnetGraph* g = nullptr;
+    for (auto& c : e->graphs)
+        if (c.key == key && std::equal(ptrs, ptrs + 6, c.ptrs)) g = &c;
+    if (!g) {
+        // capture (nothing executes here).  Every kernel's one-time set-up (dynamic-LDS attributes) was done by the uncaptured call
+        // that filled the K/V cache for this shape.
+        UnetGraph ng;
+        ng.key = key; std::copy(ptrs, ptrs + 6, ng.ptrs);
+        hipError_t err = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+        if (err == hipSuccess) {
+            try { run_plain(); } catch (...) { hipGraph_t junk = nullptr; (void)hipStreamEndCapture(e->stream, &junk); if (junk) (void)hipGraphDestroy(junk); throw; }
+            err = hipStreamEndCapture(e->stream, &ng.graph);
+            if (err == hipSuccess) err = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
+        }
+        if (err != hipSuccess) {   // no graphs on this runtime: stay on plain launches
+            (void)hipGetLastError();
+            ng.reset();
+            e->use_graphs = false;
+            run_plain();
+            return;
+        }
+        if (e->graphs.size() >= 4) { e->graphs.front().reset(); e->graphs.erase(e->graphs.begin()); }
+        e->graphs.push_back(ng);
+        g = &e->graphs.back();
+    }
+    HIP_CHECK(hipGraphLaunch(g->exec, e->stream));
 }
 
 static void vae_run(sde_engine* e, const half_t* x_packed, int B, int h, int w, int epi, float* out)
@@ -357,6 +411,7 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
         e->ctx.splitk_ws = e->splitk_ws.as<float>(); e->ctx.splitk_ws_bytes = e->splitk_ws.cap;
         if (const char* sk = getenv("SDE_SPLITK")) e->ctx.splitk_force = atoi(sk);   // tuning hook (0 = heuristic, 1 = off)
         if (const char* sp = getenv("SDE_SPLIT_MAX_HW")) e->split_max_hw = atoll(sp);
+        if (const char* gr = getenv("SDE_GRAPH")) e->use_graphs = atoi(gr) != 0;
         e->wb.ctx = e->ctx; e->wb.ctx.prof = nullptr;
         if (o.load_unet && !unet_path.empty()) {
             OnnxModel m; WeightMap w;

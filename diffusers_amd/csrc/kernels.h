@@ -125,7 +125,9 @@ void launch_f32_to_f16(const LaunchCtx& ctx, const float* x, half_t* y, int64_t 
 void launch_f16_to_f32(const LaunchCtx& ctx, const half_t* x, float* y, int64_t n);
 // NHWC fp16 -> NHWC f32 (test hook)
 // sinusoidal timestep embedding, flip_sin_to_cos=True, shift 0: out[0:dim/2]=cos, [dim/2:]=sin  (f32)
-void launch_timestep_embedding(const LaunchCtx& ctx, float t, float* out, int dim);
+// t is read from DEVICE memory (one float): a UNet call captured into a hipGraph replays with whatever timestep the scalar holds
+void launch_timestep_embedding(const LaunchCtx& ctx, const float* t_dev, float* out, int dim);
+void launch_set_scalar(const LaunchCtx& ctx, float* dst, float value);
 // y[n] = act(W[n][:] . x + bias[n]),  W fp16 [N][K], x f32 [K]; pre_silu applies SiLU to x first
 void launch_gemv(const LaunchCtx& ctx, const half_t* W, const float* x, const float* bias, float* y, int N, int K,
                  bool pre_silu, bool post_silu);

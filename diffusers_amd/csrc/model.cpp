@@ -470,20 +470,20 @@ void UNetModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b, 
     n_params = b.params;
 }
 
-void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, float timestep, const half_t* ehs_h, int S,
+void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, const float* t_dev, const half_t* ehs_h, int S,
                         half_t* const* kv_cache, bool fill_kv, float* out_nchw) const
 {
     SDE_REQUIRE(h > 0 && w > 0, SDE_ERR_INVALID_ARGUMENT, "empty latent");
     Arena& ar = *ex.arena;
     const float eps = 1e-5f;
-    // 1. time embedding: timestep is cast to int64 inside the exported graph (sd2pyke.py:121) => truncation
-    const float tt = truncf(timestep);
+    // 1. time embedding.  *t_dev holds the timestep already truncated (the exported graph casts it to int64, sd2pyke.py:121); it
+    //    lives in device memory so that a captured call can be replayed for another timestep
     float* temb = ar.get<float>(boc[0]);
     float* e1 = ar.get<float>(temb_dim);
     float* emb = ar.get<float>(temb_dim);
     float* tbias = ar.get<float>(temb_total);
     if (!ex.dry()) {
-        launch_timestep_embedding(ex.ctx, tt, temb, boc[0]);
+        launch_timestep_embedding(ex.ctx, t_dev, temb, boc[0]);
         launch_gemv(ex.ctx, time_l1.W, temb, time_l1.bias, e1, time_l1.N, time_l1.K, false, true);
         launch_gemv(ex.ctx, time_l2.W, e1, time_l2.bias, emb, time_l2.N, time_l2.K, false, false);
         launch_gemv(ex.ctx, temb_all.W, emb, temb_all.bias, tbias, temb_all.N, temb_all.K, true, false);

@@ -91,8 +91,8 @@ struct UNetModel {
     std::vector<TransformerW*> transformers;  // in kv_index order
 
     void build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b, int heads_override);
-    // kv_cache[i]: [N*S][2*C_i] per transformer; if fill_kv, (re)computed from ehs_h here
-    void forward(Exec& ex, const half_t* x_packed, int N, int h, int w, float timestep, const half_t* ehs_h, int S,
+    // kv_cache[i]: [N*S][2*C_i] per transformer; if fill_kv, (re)computed from ehs_h here.  t_dev: device float, the truncated timestep
+    void forward(Exec& ex, const half_t* x_packed, int N, int h, int w, const float* t_dev, const half_t* ehs_h, int S,
                  half_t* const* kv_cache, bool fill_kv, float* out_nchw) const;
     size_t kv_elems(int i, int N, int S) const { return (size_t)N * S * 2 * transformers[i]->C; }
     static constexpr int kInPad = 64;  // sample channels padded to one 64-wide K chunk
