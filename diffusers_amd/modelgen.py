@@ -14,8 +14,12 @@ tests/stable-diffusion/vae_decoder.onnx: Conv weights and all 
 PyTorch names; nn.Linear weights are anonymous ``onnx::MatMul_<n>`` stored [in,out]; GroupNorm
 affine parameters are anonymous ``onnx::Mul_<n>`` / ``onnx::Add_<n>`` of shape [C,1,1] behind a
 Reshape→InstanceNormalization→Reshape→Mul→Add chain; node names carry the module path.
-Shape-plumbing nodes (Shape/Gather/Concat/Cast) are abbreviated: the files are for weight
-binding by this repo's loaders, not for execution by ONNX Runtime.
+The raw dialect is a complete, EXECUTABLE opset-15 graph: sinusoidal time projection (Cast to int64 = truncation, sd2pyke.py:121),
+head split / merge through Reshape + Transpose, GEGLU as two Slices + the decomposed erf GELU, NCHW <-> token layout changes with
+Shape / Gather / Unsqueeze / Concat, and the upsample that Resizes to the SIZE of the next skip connection (the exporter traces on a
+64 x 65 latent, sd2pyke.py:287-288).  oracle/onnx_interp.py runs it as the second route from weights to UNet output
+(tests/test_oracle_unet_graph.py).  The optimizer-fused dialects (fused=True) remain weight-binding files: their com.microsoft
+nodes have no interpreter here.
 """
 from __future__ import annotations
 
@@ -224,7 +228,7 @@ _NP2ONNX = {np.dtype(np.float32): 1, np.dtype(np.int64): 7, np.dtype(np.float16)
 
 
 def _tensor(name: str, arr: np.ndarray, external: Tuple[str, int] | None = None) -> bytes:
-    arr = np.ascontiguousarray(arr)
+    arr = np.asarray(arr).copy(order="C")          # (np.ascontiguousarray would turn a 0-d scalar into shape [1])
     b = b"".join(_iv(1, int(d)) for d in arr.shape)
     b += _iv(2, _NP2ONNX[arr.dtype]) + _ld(8, name.encode())
     if external is None:
@@ -440,6 +444,27 @@ class GraphWriter:
         s = self.unary("Sigmoid", scope, x)
         return self.binary("Mul", scope, x, s)
 
+    def i64(self, scope, values) -> str:
+        return self.const(scope, np.asarray(values, np.int64))
+
+    def op(self, op, scope, inputs, attrs=b"", name=None):
+        out = self.tmp(scope, name or op)
+        self.val += 0
+        self.node(op, f"{scope}/{name or op}_{self.val}", list(inputs), [out], attrs)
+        return out
+
+    def transpose(self, scope, x, perm):
+        return self.op("Transpose", scope, [x], _attr_ints("perm", perm))
+
+    def reshape(self, scope, x, shape_name):
+        return self.op("Reshape", scope, [x, shape_name])
+
+    def dim(self, scope, shape_of, index) -> str:
+        """Shape(x)[index] as a 1-element int64 tensor (Shape -> Gather(scalar) -> Unsqueeze, as torch exports `x.shape[i]`)."""
+        shp = self.op("Shape", scope, [shape_of])
+        g = self.op("Gather", scope, [shp, self.const(scope, np.asarray(index, np.int64))], _attr_i("axis", 0))
+        return self.op("Unsqueeze", scope, [g, self.i64(scope, [0])])
+
     def serialize(self, path: str, inputs: Sequence[str], outputs: Sequence[str], external_file: str | None):
         """Streams the ModelProto to disk piece by piece (no quadratic byte-string concatenation)."""
         base = os.path.dirname(os.path.abspath(path))
@@ -496,6 +521,7 @@ def _emit_resnet(gw: GraphWriter, scope, p, w, x, emb, eps, groups):
     if emb is not None and (p + ".time_emb_proj.weight") in w:
         e = gw.silu(scope + "/nonlinearity_1", emb)
         e = gw.gemm(scope + "/time_emb_proj", p + ".time_emb_proj", w, e)
+        e = gw.op("Unsqueeze", scope, [e, gw.i64(scope, [2, 3])])          # temb[:, :, None, None]
         h = gw.binary("Add", scope, h, e)
     h = gw.group_norm(scope + "/norm2", p + ".norm2", w, h, eps, groups)
     h = gw.silu(scope + "/nonlinearity_2", h)
@@ -538,21 +564,34 @@ def _emit_attention(gw: GraphWriter, scope, p, w, x, ctx, heads, c):
     k = gw.linear(scope + "/to_k", p + ".to_k", w, ctx, bias=False)
     v = gw.linear(scope + "/to_v", p + ".to_v", w, ctx, bias=False)
     d = c // heads
-    # head split: Reshape to [B, S, heads, d] — constants as torch would fold them
+    # head split: [B, S, C] -> [B, S, heads, d] -> [B, heads, S, d]; scores = q k^T * d^-1/2; merge back to [B, S, C]
     shp = gw.const(scope, np.asarray([0, -1, heads, d], np.int64))
-    q = gw.binary("Reshape", scope, q, shp)
-    k = gw.binary("Reshape", scope, k, shp, "Reshape_1")
-    v = gw.binary("Reshape", scope, v, shp, "Reshape_2")
+    q = gw.transpose(scope, gw.binary("Reshape", scope, q, shp), [0, 2, 1, 3])
+    k = gw.transpose(scope, gw.binary("Reshape", scope, k, shp, "Reshape_1"), [0, 2, 3, 1])
+    v = gw.transpose(scope, gw.binary("Reshape", scope, v, shp, "Reshape_2"), [0, 2, 1, 3])
     s = gw.binary("MatMul", scope, q, k)
     s = gw.binary("Mul", scope, s, gw.const(scope, np.asarray(d ** -0.5, np.float32)))
-    s = gw.unary("Softmax", scope, s)
+    s = gw.op("Softmax", scope, [s], _attr_i("axis", -1))
     o = gw.binary("MatMul", scope, s, v, "MatMul_1")
+    o = gw.transpose(scope, o, [0, 2, 1, 3])
+    o = gw.binary("Reshape", scope, o, gw.const(scope, np.asarray([0, -1, c], np.int64)), "Reshape_3")
     return gw.linear(scope + "/to_out.0", p + ".to_out.0", w, o, bias=True)
 
 
 def _emit_transformer(gw: GraphWriter, scope, p, w, x, ctx, heads, c, lin, groups):
     h = gw.group_norm(scope + "/norm", p + ".norm", w, x, 1e-6, groups)
-    h = gw.linear(scope + "/proj_in", p + ".proj_in", w, h) if lin else gw.conv(scope + "/proj_in", p + ".proj_in", w, h, k=1)
+    raw = not gw.fused
+    if raw:
+        # NCHW -> tokens [N, H*W, C]: conv projection first (SD1.x), Linear projection after the layout change (SD2.x)
+        tok = gw.const(scope, np.asarray([0, -1, c], np.int64))
+        if lin:
+            h = gw.reshape(scope, gw.transpose(scope, h, [0, 2, 3, 1]), tok)
+            h = gw.linear(scope + "/proj_in", p + ".proj_in", w, h)
+        else:
+            h = gw.conv(scope + "/proj_in", p + ".proj_in", w, h, k=1)
+            h = gw.reshape(scope, gw.transpose(scope, h, [0, 2, 3, 1]), tok)
+    else:
+        h = gw.linear(scope + "/proj_in", p + ".proj_in", w, h) if lin else gw.conv(scope + "/proj_in", p + ".proj_in", w, h, k=1)
     bs, bp = scope + "/transformer_blocks.0", p + ".transformer_blocks.0"
     n = gw.layer_norm(bs + "/norm1", bp + ".norm1", w, h)
     if gw.nv:
@@ -582,13 +621,30 @@ def _emit_transformer(gw: GraphWriter, scope, p, w, x, ctx, heads, c, lin, group
                 gw.node("Gelu", gw.fname("Gelu"), [y], [g], b"", "com.microsoft")
             y = gw.binary("Mul", bs + "/ff/net.0", y, g)
         else:
-            # exact-erf GELU on the gate half (fusion_gelu.py:27-45 pattern), value half first
-            g = gw.binary("Div", bs + "/ff/net.0", y, gw.const(bs, np.asarray(1.4142135381698608, np.float32)))
-            g = gw.unary("Erf", bs + "/ff/net.0", g)
-            y = gw.binary("Mul", bs + "/ff/net.0", y, g)
+            # GEGLU (fusion_biassplitgelu.py:20-32): value = first half, gate = second half; exact-erf GELU on the gate as
+            # x -> Div(sqrt 2) -> Erf -> Add(1) -> Mul(x) -> Mul(0.5) (fusion_gelu.py:27-45)
+            fs = bs + "/ff/net.0"
+            val = gw.op("Slice", fs, [y, gw.i64(fs, [0]), gw.i64(fs, [4 * c]), gw.i64(fs, [-1])])
+            gate = gw.op("Slice", fs, [y, gw.i64(fs, [4 * c]), gw.i64(fs, [8 * c]), gw.i64(fs, [-1])], name="Slice_1")
+            g = gw.binary("Div", fs, gate, gw.const(bs, np.asarray(1.4142135381698608, np.float32)))
+            g = gw.unary("Erf", fs, g)
+            g = gw.binary("Add", fs, g, gw.const(bs, np.asarray(1.0, np.float32)))
+            g = gw.binary("Mul", fs, gate, g, "Mul_1")
+            g = gw.binary("Mul", fs, g, gw.const(bs, np.asarray(0.5, np.float32)), "Mul_2")
+            y = gw.binary("Mul", fs, val, g, "Mul_3")
         y = gw.linear(bs + "/ff/net.2", bp + ".ff.net.2", w, y)
         h = gw.binary("Add", bs, h, y, "Add_2")
-    h = gw.linear(scope + "/proj_out", p + ".proj_out", w, h) if lin else gw.conv(scope + "/proj_out", p + ".proj_out", w, h, k=1)
+    if raw:
+        # tokens -> NCHW with the batch / height / width of the block input
+        nhwc = gw.op("Concat", scope, [gw.dim(scope, x, 0), gw.dim(scope, x, 2), gw.dim(scope, x, 3), gw.i64(scope, [c])], _attr_i("axis", 0))
+        if lin:
+            h = gw.linear(scope + "/proj_out", p + ".proj_out", w, h)
+            h = gw.transpose(scope, gw.reshape(scope, h, nhwc), [0, 3, 1, 2])
+        else:
+            h = gw.transpose(scope, gw.reshape(scope, h, nhwc), [0, 3, 1, 2])
+            h = gw.conv(scope + "/proj_out", p + ".proj_out", w, h, k=1)
+    else:
+        h = gw.linear(scope + "/proj_out", p + ".proj_out", w, h) if lin else gw.conv(scope + "/proj_out", p + ".proj_out", w, h, k=1)
     return gw.binary("Add", scope, h, x)
 
 
@@ -597,8 +653,18 @@ def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.flo
     gw = GraphWriter(dtype, fused, approximate_gelu, nv)
     boc = list(cfg["block_out_channels"])
     lpb, lin, groups, eps = cfg["layers_per_block"], cfg["use_linear_projection"], cfg["norm_num_groups"], cfg["norm_eps"]
-    t = gw.unary("Cast", "", "timestep")
-    t = gw.unary("Sin", "/time_proj", t)  # sinusoid plumbing abbreviated
+    if fused:
+        t = gw.unary("Cast", "", "timestep")
+        t = gw.unary("Sin", "/time_proj", t)  # binding-only file: sinusoid plumbing abbreviated
+    else:
+        # timestep.long() (sd2pyke.py:121: truncation) -> Timesteps(boc[0], flip_sin_to_cos=True, freq_shift=0): [cos | sin] of t * 10000^(-k/half)
+        half = boc[0] // 2
+        ti = gw.op("Cast", "", ["timestep"], _attr_i("to", 7))
+        tf = gw.op("Cast", "/time_proj", [ti], _attr_i("to", 1))
+        tf = gw.op("Unsqueeze", "/time_proj", [tf, gw.i64("/time_proj", [1])])
+        freqs = np.exp(-np.log(np.float32(10000.0)) * np.arange(half, dtype=np.float32) / np.float32(half)).astype(np.float32)[None]
+        arg = gw.binary("Mul", "/time_proj", tf, gw.const("/time_proj", freqs))
+        t = gw.op("Concat", "/time_proj", [gw.unary("Cos", "/time_proj", arg), gw.unary("Sin", "/time_proj", arg)], _attr_i("axis", -1))
     e = gw.gemm("/time_embedding/linear_1", "time_embedding.linear_1", w, t)
     e = gw.silu("/time_embedding/act", e)
     emb = gw.gemm("/time_embedding/linear_2", "time_embedding.linear_2", w, e)
@@ -634,9 +700,14 @@ def write_unet_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.flo
         if i < len(boc) - 1:
             sc = f"/up_blocks.{i}/upsamplers.0"
             r = gw.tmp(sc, "Resize")
-            gw.node("Resize", sc + "/Resize", [h, "", gw.const(sc, np.asarray([1, 1, 2, 2], np.float32))], [r],
-                    _attr_s("coordinate_transformation_mode", "asymmetric") + _attr_s("mode", "nearest") +
-                    _attr_s("nearest_mode", "floor"))
+            rattr = _attr_s("coordinate_transformation_mode", "asymmetric") + _attr_s("mode", "nearest") + _attr_s("nearest_mode", "floor")
+            if fused:
+                gw.node("Resize", sc + "/Resize", [h, "", gw.const(sc, np.asarray([1, 1, 2, 2], np.float32))], [r], rattr)
+            else:
+                # forward_upsample_size: F.interpolate(h, size = the next skip connection's H x W)
+                nc = gw.op("Slice", sc, [gw.op("Shape", sc, [h]), gw.i64(sc, [0]), gw.i64(sc, [2]), gw.i64(sc, [0])])
+                hw = gw.op("Slice", sc, [gw.op("Shape", sc, [skips[-1]]), gw.i64(sc, [2]), gw.i64(sc, [4]), gw.i64(sc, [0])], name="Slice_1")
+                gw.node("Resize", sc + "/Resize", [h, "", "", gw.op("Concat", sc, [nc, hw], _attr_i("axis", 0))], [r], rattr)
             h = gw.conv(sc + "/conv", f"up_blocks.{i}.upsamplers.0.conv", w, r)
     h = gw.group_norm("/conv_norm_out", "conv_norm_out", w, h, eps, groups, swish=True)
     if not gw.fused:

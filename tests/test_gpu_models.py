@@ -73,6 +73,19 @@ def test_unet_forward_vs_oracle(pipe, pipe_plain, oracle_models, N, h, w, S, t):
     assert rel_l2(got, plain) < 1e-2
 
 
+def test_unet_vs_graph_interpreter(pipe, tiny_model_dir):
+    """The engine against the SECOND route: the very unet.onnx it loaded, executed node by node by the ONNX interpreter
+    (pinned on the reference's own exports, tests/test_oracle_fixture_graphs.py) instead of the functional restatement."""
+    from oracle import onnx_interp, onnx_io
+    m = onnx_io.load(os.path.join(tiny_model_dir, "unet.onnx"))
+    rng = np.random.default_rng(404)
+    for N, h, w, S, t in [(2, 16, 16, 77, 603.7), (1, 15, 17, 152, 41.0)]:
+        x = rng.standard_normal((N, 4, h, w)).astype(np.float32)
+        ehs = (rng.standard_normal((N, S, 64)) * 0.5).astype(np.float32)
+        ref = onnx_interp.run(m, {"sample": x, "timestep": np.asarray([t], np.float32), "encoder_hidden_states": ehs})["out_sample"]
+        assert rel_l2(pipe.unet(x, t, ehs), ref) < 1e-2
+
+
 def test_timestep_truncation(pipe):
     """The exported graph casts timestep to int64 (sd2pyke.py:121): 946.42 and 946.0 must give identical outputs."""
     rng = np.random.default_rng(0)
