@@ -96,3 +96,38 @@ def test_fused_dialect_writer_follows_the_optimizer_packing(tmp_path):
     gn = [n for n in m.nodes if n.op_type == "GroupNorm"][0]
     assert gn.inputs[1] == gn.name + "_gamma" and gn.attr_i("activation") == 1 and gn.attr_i("groups") == 32
     assert np.array_equal(m.weight(gn.inputs[1]), w["down_blocks.0.resnets.0.norm1.weight"])
+
+
+def test_rust_sys_crate_declares_the_whole_abi():
+    """rust/sdengine-sys/src/lib.rs (source only: no Rust toolchain here) must declare exactly the entry points of
+    include/sdengine.h, and its struct mirrors must list the header's fields in the header's order."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "sdengine.h")).read()
+    rs = open(os.path.join(root, "rust", "sdengine-sys", "src", "lib.rs")).read()
+    c_fns = set(re.findall(r"\b(sde_[a-z0-9_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    c_fns -= {"sde_callback_fn", "sde_exchange_fn"}
+    rs_fns = set(re.findall(r"pub fn (sde_[a-z0-9_]+)\s*\(", rs))
+    assert c_fns == rs_fns, (sorted(c_fns - rs_fns), sorted(rs_fns - c_fns))
+    from diffusers_amd import _lib
+    assert rs_fns == set(_lib.SYMBOLS)
+
+    def c_fields(name):
+        body = re.search(r"typedef struct " + name + r" \{(.*?)\} " + name + ";", hdr, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for part in decl.split(","):
+                out.append(re.sub(r"\[.*?\]", "", part.strip().split()[-1].lstrip("*")))
+        return out
+
+    def rs_fields(name):
+        body = re.search(r"pub struct " + name + r" \{(.*?)\}\n", rs, flags=re.S).group(1)
+        return re.findall(r"pub ([a-z_0-9]+):", body)
+
+    for st in ("sde_engine_opts", "sde_sched_cfg", "sde_run_stats", "sde_model_info", "sde_kernel_stat", "sde_txt2img_opts"):
+        cf, rf = [f.lower() for f in c_fields(st)], rs_fields(st)
+        assert cf == rf, (st, cf, rf)
