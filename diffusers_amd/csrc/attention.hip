@@ -571,6 +571,7 @@ static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
 void launch_attention(const LaunchCtx& ctx, const AttnArgs& a)
 {
     SDE_REQUIRE(a.NB > 0 && a.heads > 0 && a.Sq > 0 && a.Skv > 0 && a.d > 0, SDE_ERR_INVALID_ARGUMENT, "attention: empty problem");
+    if (ctx.f32) { f32_launch_attention(ctx, a); return; }
     AttnDev p{a.Q, a.K, a.V, a.O, a.ldq, a.ldk, a.ldv, a.ldo, a.NB, a.heads, a.Sq, a.Skv, a.d,
               a.scale * 1.44269504088896340736f};
     const double flops = 4.0 * a.NB * a.heads * (double)a.Sq * a.Skv * a.d;

@@ -19,6 +19,7 @@ __global__ void pack_nchw_kernel(const float* x, half_t* y, int NB, int C, int H
 }
 void launch_pack_nchw(const LaunchCtx& ctx, const float* x, half_t* y, int NB, int C, int H, int W, int Cpad, float scale)
 {
+    if (ctx.f32) { f32_launch_pack_nchw(ctx, x, y, NB, C, H, W, Cpad, scale); return; }
     ProfScope ps(ctx, "pack_nchw", 0, (double)NB * H * W * (C * 4.0 + Cpad * 2.0));
     long long total = (long long)NB * H * W * Cpad;
     int blocks = (int)std::min<long long>(cdiv64(total, 256), 4096);
@@ -41,6 +42,7 @@ __global__ void pack_latents_kernel(const float* lat, half_t* packed, int B, int
 void launch_pack_latents(const LaunchCtx& ctx, const float* latents, half_t* packed, int B, int dup, int C, int H, int W, int Cpad,
                          float scale)
 {
+    if (ctx.f32) { f32_launch_pack_latents(ctx, latents, packed, B, dup, C, H, W, Cpad, scale); return; }
     ProfScope ps(ctx, "pack_latents", 0, (double)B * C * H * W * (4.0 + 2.0 * dup));
     long long total = (long long)B * C * H * W;
     hipLaunchKernelGGL(pack_latents_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 2048)), dim3(256), 0, ctx.stream,
@@ -58,6 +60,7 @@ __global__ void f16_to_f32_kernel(const half_t* x, float* y, long long n)
 }
 void launch_f32_to_f16(const LaunchCtx& ctx, const float* x, half_t* y, int64_t n)
 {
+    if (ctx.f32) { HIP_CHECK(hipMemcpyAsync(y, x, (size_t)n * 4, hipMemcpyDeviceToDevice, ctx.stream)); return; }   // fp32 engine: a copy
     ProfScope ps(ctx, "cast_f32_f16", 0, 6.0 * n);
     hipLaunchKernelGGL(f32_to_f16_kernel, dim3((unsigned)std::min<long long>(cdiv64(n, 256), 4096)), dim3(256), 0, ctx.stream, x, y, (long long)n);
     HIP_CHECK(hipGetLastError());
@@ -124,6 +127,7 @@ __global__ void gemv_kernel(const half_t* W, const float* x, const float* bias, 
 void launch_gemv(const LaunchCtx& ctx, const half_t* W, const float* x, const float* bias, float* y, int N, int K, bool pre_silu,
                  bool post_silu)
 {
+    if (ctx.f32) { f32_launch_gemv(ctx, W, x, bias, y, N, K, pre_silu, post_silu); return; }
     SDE_REQUIRE(K % 8 == 0, SDE_ERR_INVALID_ARGUMENT, "gemv: K must be a multiple of 8");
     ProfScope ps(ctx, "gemv_time_mlp", 2.0 * N * K, 2.0 * N * K);
     hipLaunchKernelGGL(gemv_kernel, dim3(cdiv(N, 4)), dim3(256), 0, ctx.stream, W, x, bias, y, N, K, pre_silu ? 1 : 0, post_silu ? 1 : 0);
@@ -158,7 +162,7 @@ void launch_approx_decode(const LaunchCtx& ctx, const float* lat, float* img, in
 struct RepackDev {
     const void* src; int src_is_f16;
     int O, I, KH, KW, in_out;
-    half_t* dst; int dst_row0, Ipad, i0, Kdst, geglu_half, geglu_pair, src_i0, nI;
+    half_t* dst; int dst_row0, Ipad, i0, Kdst, geglu_half, geglu_pair, src_i0, nI, dst_f32;
 };
 __global__ void repack_kernel(RepackDev a)
 {
@@ -184,14 +188,15 @@ __global__ void repack_kernel(RepackDev a)
         const int c = a.i0 + i, taps = a.KH * a.KW;
         const int ck = (taps > 1 && a.Ipad % 64 == 0) ? 64 : a.Ipad;
         const long long kcol = ((long long)(c / ck) * taps + tap) * ck + c % ck;
-        a.dst[(long long)(a.dst_row0 + row) * a.Kdst + kcol] = (half_t)v;
+        if (a.dst_f32) ((float*)a.dst)[(long long)(a.dst_row0 + row) * a.Kdst + kcol] = v;
+        else a.dst[(long long)(a.dst_row0 + row) * a.Kdst + kcol] = (half_t)v;
     }
 }
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& r)
 {
     const int nI = r.src_I > 0 ? r.src_I : r.I;
     SDE_REQUIRE(r.src_i0 >= 0 && r.src_i0 + nI <= r.I, SDE_ERR_INVALID_ARGUMENT, "repack: source channel range");
-    RepackDev a{r.src, r.src_is_f16, r.O, r.I, r.KH, r.KW, r.in_out, r.dst, r.dst_row0, r.Ipad, r.i0, r.Kdst, r.geglu_half, r.geglu_pair, r.src_i0, nI};
+    RepackDev a{r.src, r.src_is_f16, r.O, r.I, r.KH, r.KW, r.in_out, r.dst, r.dst_row0, r.Ipad, r.i0, r.Kdst, r.geglu_half, r.geglu_pair, r.src_i0, nI, r.dst_f32};
     long long total = (long long)a.O * nI * a.KH * a.KW;
     hipLaunchKernelGGL(repack_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 8192)), dim3(256), 0, ctx.stream, a);
     HIP_CHECK(hipGetLastError());
@@ -210,7 +215,7 @@ struct StepDev {
     const float* model_out; float* latents; const float* noise;
     float c[12]; int clip, dpm_algo;
     float* hist[4]; int nhist; float lms_c[4];
-    float next_scale; half_t* next_input; int Cpad;
+    float next_scale; half_t* next_input; int Cpad, next_f32;
     float* eps_out;
 };
 
@@ -304,9 +309,16 @@ __global__ void cfg_step_kernel(StepDev a)
             int pix = (int)(i % a.HW);
             int c = (int)((i / a.HW) % a.C);
             int b = (int)(i / ((long long)a.HW * a.C));
-            half_t v = (half_t)(prev * a.next_scale);
-            a.next_input[((long long)b * a.HW + pix) * a.Cpad + c] = v;
-            if (a.cfg) a.next_input[((long long)(b + a.B) * a.HW + pix) * a.Cpad + c] = v;
+            if (a.next_f32) {
+                float* ni = (float*)a.next_input;
+                const float v = prev * a.next_scale;
+                ni[((long long)b * a.HW + pix) * a.Cpad + c] = v;
+                if (a.cfg) ni[((long long)(b + a.B) * a.HW + pix) * a.Cpad + c] = v;
+            } else {
+                half_t v = (half_t)(prev * a.next_scale);
+                a.next_input[((long long)b * a.HW + pix) * a.Cpad + c] = v;
+                if (a.cfg) a.next_input[((long long)(b + a.B) * a.HW + pix) * a.Cpad + c] = v;
+            }
         }
     }
 }
@@ -319,7 +331,7 @@ void launch_cfg_step(const LaunchCtx& ctx, const StepArgs& s)
     for (int i = 0; i < 12; ++i) a.c[i] = s.c[i];
     a.clip = s.clip; a.dpm_algo = s.dpm_algo;
     for (int i = 0; i < 4; ++i) { a.hist[i] = s.hist[i]; a.lms_c[i] = s.lms_c[i]; }
-    a.nhist = s.nhist; a.next_scale = s.next_input_scale; a.next_input = s.next_input; a.Cpad = s.Cpad; a.eps_out = s.eps_out;
+    a.nhist = s.nhist; a.next_scale = s.next_input_scale; a.next_input = s.next_input; a.Cpad = s.Cpad; a.eps_out = s.eps_out; a.next_f32 = s.next_input_f32;
     SDE_REQUIRE(!((s.kind == STEP_EULER_A) && !s.noise), SDE_ERR_INVALID_ARGUMENT, "cfg_step: Euler-a needs a noise tensor");
     const long long per = (long long)s.B * s.C * s.H * s.W;
     const double bytes = per * ((s.cfg ? 8.0 : 4.0) + 8.0 + (s.noise ? 4.0 : 0.0) + (s.next_input ? (s.cfg ? 4.0 : 2.0) : 0.0) + 4.0 * s.nhist);

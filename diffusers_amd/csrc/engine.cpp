@@ -202,11 +202,11 @@ static void setup_kv(sde_engine* e, int N, int S)
 {
     size_t total = 0;
     for (int i = 0; i < e->unet.n_transformers; ++i) total += (e->unet.kv_elems(i, N, S) + 127) & ~(size_t)127;
-    e->kvbuf.ensure(total * sizeof(half_t));
+    e->kvbuf.ensure(total * e->ctx.esize());
     e->kv_ptrs.resize((size_t)e->unet.n_transformers);
     size_t off = 0;
     for (int i = 0; i < e->unet.n_transformers; ++i) {
-        e->kv_ptrs[(size_t)i] = e->kvbuf.as<half_t>() + off;
+        e->kv_ptrs[(size_t)i] = (half_t*)(e->kvbuf.as<char>() + off * e->ctx.esize());
         off += (e->unet.kv_elems(i, N, S) + 127) & ~(size_t)127;
     }
 }
@@ -218,7 +218,7 @@ static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w,
     SDE_REQUIRE(e->has_unet, SDE_ERR_MODEL, "engine was created without a UNet");
     const long long key = ((long long)N << 40) ^ ((long long)h << 28) ^ ((long long)w << 16) ^ S;
     if (key != e->unet_key) {
-        Arena dry; dry.dry = true;
+        Arena dry; dry.dry = true; dry.act_bytes = e->ctx.esize();
         Exec dx{e->ctx, &dry, e->split_max_hw};
         std::vector<half_t*> fake((size_t)e->unet.n_transformers, (half_t*)nullptr);
         e->unet.forward(dx, nullptr, N, h, w, nullptr, nullptr, S, fake.data(), true, nullptr);
@@ -229,7 +229,7 @@ static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w,
     // the exported graph casts the timestep to int64 (sd2pyke.py:121): truncation
     launch_set_scalar(e->ctx, e->t_dev.as<float>(), truncf(t));
     auto run_plain = [&] {
-        e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false;
+        e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false; e->arena.act_bytes = e->ctx.esize();
         Exec ex{e->ctx, &e->arena, e->split_max_hw};
         e->unet.forward(ex, x_packed, N, h, w, e->t_dev.as<float>(), ehs_h, S, e->kv_ptrs.data(), fill_kv, out);
     };
@@ -269,13 +269,13 @@ static void vae_run(sde_engine* e, const half_t* x_packed, int B, int h, int w, 
     SDE_REQUIRE(e->has_vae, SDE_ERR_MODEL, "engine was created without a VAE decoder");
     const long long key = ((long long)B << 40) ^ ((long long)h << 20) ^ w;
     if (key != e->vae_key) {
-        Arena dry; dry.dry = true;
+        Arena dry; dry.dry = true; dry.act_bytes = e->ctx.esize();
         Exec dx{e->ctx, &dry};
         e->vae.forward(dx, nullptr, B, h, w, epi, nullptr);
         e->vae_peak = dry.peak; e->vae_key = key;
     }
     ensure_arena(e, std::max(e->unet_peak, e->vae_peak));
-    e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false;
+    e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false; e->arena.act_bytes = e->ctx.esize();
     Exec ex{e->ctx, &e->arena};
     e->vae.forward(ex, x_packed, B, h, w, epi, out);
 }
@@ -291,7 +291,7 @@ static void decode_dev(sde_engine* e, const float* d_latents, int B, int h, int 
     const int up = e->vae.upscale();
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
-        e->vae_in.ensure((size_t)nb * h * w * VaeDecoderModel::kInPad * sizeof(half_t));
+        e->vae_in.ensure((size_t)nb * h * w * VaeDecoderModel::kInPad * e->ctx.esize());
         launch_pack_nchw(e->ctx, d_latents + (size_t)b0 * e->vae.latent_channels * h * w, e->vae_in.as<half_t>(), nb, e->vae.latent_channels, h, w,
                          VaeDecoderModel::kInPad, scale);
         vae_run(e, e->vae_in.as<half_t>(), nb, h, w, epi, d_out + (size_t)b0 * e->vae.out_channels * h * up * w * up);
@@ -320,14 +320,14 @@ static void decode_on_lane(sde_engine* e, PreviewLane& L, const float* d_latents
     const int chunk = std::max(1, std::min(B, 8)), up = e->vae.upscale();
     const long long key = ((long long)chunk << 40) ^ ((long long)h << 20) ^ w;
     if (key != L.key) {
-        Arena dry; dry.dry = true;
+        Arena dry; dry.dry = true; dry.act_bytes = e->ctx.esize();
         Exec dx{L.ctx, &dry};
         e->vae.forward(dx, nullptr, chunk, h, w, EPI_IMAGE, nullptr);
         L.peak = dry.peak; L.key = key;
     }
     if (L.peak > L.arena_buf.cap) { HIP_CHECK(hipStreamSynchronize(L.stream)); L.arena_buf.ensure(L.peak + (L.peak >> 3)); }
-    L.arena.base = L.arena_buf.as<char>(); L.arena.cap = L.arena_buf.cap; L.arena.dry = false;
-    L.vae_in.ensure((size_t)chunk * h * w * VaeDecoderModel::kInPad * sizeof(half_t));
+    L.arena.base = L.arena_buf.as<char>(); L.arena.cap = L.arena_buf.cap; L.arena.dry = false; L.arena.act_bytes = e->ctx.esize();
+    L.vae_in.ensure((size_t)chunk * h * w * VaeDecoderModel::kInPad * e->ctx.esize());
     for (int b0 = 0; b0 < B; b0 += chunk) {
         const int nb = std::min(chunk, B - b0);
         launch_pack_nchw(L.ctx, d_latents + (size_t)b0 * e->vae.latent_channels * h * w, L.vae_in.as<half_t>(), nb, e->vae.latent_channels, h, w,
@@ -391,7 +391,8 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
         *out = nullptr;
         sde_engine_opts o;
         if (opts_in) o = *opts_in; else sde_engine_opts_default(&o);
-        SDE_REQUIRE(o.dtype == SDE_F16, SDE_ERR_INVALID_ARGUMENT, "only dtype f16 is implemented in this build (bf16/f32 engines are not)");
+        SDE_REQUIRE(o.dtype == SDE_F16 || o.dtype == SDE_F32, SDE_ERR_INVALID_ARGUMENT,
+                    "engine dtype must be f16 (MFMA kernels, the benchmarked path) or f32 (plain fp32 kernels, the reference's own precision); bf16 is not implemented");
         int ndev = sde_device_count();
         SDE_REQUIRE(ndev > 0, SDE_ERR_DEVICE, "no HIP device visible: the engine has no CPU fallback");
         SDE_REQUIRE(o.device_id >= 0 && o.device_id < ndev, SDE_ERR_DEVICE, "device_id out of range");
@@ -407,10 +408,12 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
         e->prof.stream = e->stream;
         e->zeros.ensure(4096, true, e->stream);
         e->ctx.stream = e->stream; e->ctx.prof = &e->prof; e->ctx.zeros = e->zeros.as<half_t>(); e->ctx.force_naive = o.force_naive != 0;
+        e->ctx.f32 = o.dtype == SDE_F32;
+        if (e->ctx.f32) e->split_max_hw = 0;   // floats need no low parts
         e->splitk_ws.ensure((size_t)64 << 20);
         e->ctx.splitk_ws = e->splitk_ws.as<float>(); e->ctx.splitk_ws_bytes = e->splitk_ws.cap;
         if (const char* sk = getenv("SDE_SPLITK")) e->ctx.splitk_force = atoi(sk);   // tuning hook (0 = heuristic, 1 = off)
-        if (const char* sp = getenv("SDE_SPLIT_MAX_HW")) e->split_max_hw = atoll(sp);
+        if (const char* sp = getenv("SDE_SPLIT_MAX_HW")) { if (!e->ctx.f32) e->split_max_hw = atoll(sp); }
         if (const char* gr = getenv("SDE_GRAPH")) e->use_graphs = atoi(gr) != 0;
         e->wb.ctx = e->ctx; e->wb.ctx.prof = nullptr;
         if (o.load_unet && !unet_path.empty()) {
@@ -503,8 +506,8 @@ static void unet_forward_dev_locked(sde_engine* e, const float* d_sample, int N,
                                     float* d_out)
 {
     const int Cp = UNetModel::kInPad;
-    e->x_packed.ensure((size_t)N * h * w * Cp * sizeof(half_t));
-    e->ehs_h.ensure((size_t)N * S * D * sizeof(half_t));
+    e->x_packed.ensure((size_t)N * h * w * Cp * e->ctx.esize());
+    e->ehs_h.ensure((size_t)N * S * D * e->ctx.esize());
     setup_kv(e, N, S);
     launch_pack_nchw(e->ctx, d_sample, e->x_packed.as<half_t>(), N, e->unet.in_channels, h, w, Cp, 1.0f);
     launch_f32_to_f16(e->ctx, d_ehs, e->ehs_h.as<half_t>(), (int64_t)N * S * D);
@@ -798,9 +801,9 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         // ---- device state
         e->latents.ensure(per * 4);
         e->model_out.ensure((size_t)N * C * h * w * 4);
-        e->x_packed.ensure((size_t)N * h * w * Cp * sizeof(half_t));
-        HIP_CHECK(hipMemsetAsync(e->x_packed.p, 0, (size_t)N * h * w * Cp * sizeof(half_t), st));
-        e->ehs_h.ensure((size_t)N * S * D * sizeof(half_t));
+        e->x_packed.ensure((size_t)N * h * w * Cp * e->ctx.esize());
+        HIP_CHECK(hipMemsetAsync(e->x_packed.p, 0, (size_t)N * h * w * Cp * e->ctx.esize(), st));
+        e->ehs_h.ensure((size_t)N * S * D * e->ctx.esize());
         setup_kv(e, Nu, S);
         float* d_lat = e->latents.as<float>();
         std::vector<float> host_tmp;
@@ -857,7 +860,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         for (int i = 0; i < nt; ++i) {
             const float t = ts[(size_t)i];
             const auto tq0 = std::chrono::steady_clock::now();
-            unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, e->ehs_h.as<half_t>() + half_off * B * S * D, S, i == 0,
+            unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, (const half_t*)(e->ehs_h.as<char>() + half_off * B * S * D * e->ctx.esize()), S, i == 0,
                      e->model_out.as<float>() + half_off * per);                                             // :283
             enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
             if (pending_cb) {
@@ -906,7 +909,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
                 a.rescale_factor = ws;
             }
             if (i + 1 < nt) {
-                a.next_input = e->x_packed.as<half_t>(); a.Cpad = Cp;
+                a.next_input = e->x_packed.as<half_t>(); a.Cpad = Cp; a.next_input_f32 = e->ctx.f32 ? 1 : 0;
                 a.next_input_scale = 1.0f / sch->input_scale_divisor(ts[(size_t)i + 1]);
             }
             if (want_taps) a.eps_out = e->taps.as<float>();
@@ -1025,7 +1028,7 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
         EngineLock lk(e);
         engine_activate(e);
-        LaunchCtx ctx = e->ctx; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3;   // 0 fast, 1 plain, 2 / 3 force the 256x320 / 256x160 kernel
+        LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3;   // 0 fast, 1 plain, 2 / 3 force the 256x320 / 256x160 kernel
         const int taps = ksize * ksize;
         // upsample: 1 = nearest 2x; 2 = 2x cropped to (2*Hi - 1) x (2*Wi - 1), the UNet's upsample-to-skip-size on odd latents
         const int Hv = upsample ? 2 * Hi - (upsample == 2) : Hi, Wv = upsample ? 2 * Wi - (upsample == 2) : Wi;
@@ -1061,7 +1064,7 @@ sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const fl
         SDE_REQUIRE(e && q && k && v && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
         EngineLock lk(e);
         engine_activate(e);
-        LaunchCtx ctx = e->ctx; ctx.force_naive = naive != 0;
+        LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive != 0;
         const int C = heads * d;
         const size_t nq = (size_t)NB * Sq * C, nk = (size_t)NB * Skv * C;
         DevBuf f, qh, kh, vh, oh, of;

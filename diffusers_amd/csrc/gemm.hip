@@ -370,6 +370,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     if (a.taps == 9)
         SDE_REQUIRE(a.M % (a.Ho * a.Wo) == 0 && a.Ho > 0 && a.Wo > 0 && a.Hi > 0 && a.Wi > 0, SDE_ERR_INVALID_ARGUMENT,
                     "launch_gemm: conv geometry");
+    if (ctx.f32) { f32_launch_gemm(ctx, a); return; }
     GemmDev p = to_dev(ctx, a);
     const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
     const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (1 + (a.R ? 1 : 0) + (a.Rlo ? 1 : 0) + (a.Dlo ? 1 : 0))) * 2.0 * a.batch;

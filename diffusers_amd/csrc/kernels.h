@@ -20,7 +20,23 @@ struct LaunchCtx {
     float* splitk_ws = nullptr;     // fp32 partial-tile workspace for split-K GEMMs (null: split-K off)
     size_t splitk_ws_bytes = 0;
     int splitk_force = 0;           // tuning hook: >0 forces this split factor where split-K applies
+    // fp32 engine (sde_engine_opts.dtype = SDE_F32): every activation / weight pointer declared `half_t*` below addresses FLOATS and
+    // every launcher forwards to its fp32 kernel in f32path.hip.  Element counts, strides and layouts are unchanged.
+    bool f32 = false;
+    size_t esize() const { return f32 ? 4 : 2; }
 };
+// f32path.hip
+struct GemmArgs; struct AttnArgs; struct GroupNormArgs;
+void f32_launch_gemm(const LaunchCtx& ctx, const GemmArgs& a);
+void f32_launch_geglu(const LaunchCtx& ctx, const half_t* X, half_t* Y, int64_t rows, int half_n, int tanh_form);
+void f32_launch_attention(const LaunchCtx& ctx, const AttnArgs& a);
+void f32_launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a);
+void f32_launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows, int C,
+                              const float* gamma, const float* beta, float eps);
+void f32_launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, int64_t n);
+void f32_launch_pack_nchw(const LaunchCtx& ctx, const float* x, half_t* y, int NB, int C, int H, int W, int Cpad, float scale);
+void f32_launch_pack_latents(const LaunchCtx& ctx, const float* latents, half_t* packed, int B, int dup, int C, int H, int W, int Cpad, float scale);
+void f32_launch_gemv(const LaunchCtx& ctx, const half_t* W, const float* x, const float* bias, float* y, int N, int K, bool pre_silu, bool post_silu);
 // RAII bracket: records HIP events around a launch when profiling is on.
 // Raises a kernel's dynamic-LDS limit once per (device, kernel): the attribute is per device, and engines on several GPUs (or on
 // several host threads) may share this process.
@@ -146,6 +162,7 @@ struct RepackArgs {
     int geglu_half = 0;                        // >0: row o -> interleaved row (16-block value/gate), value = geglu_half
     int geglu_pair = 0;                        // with geglu_half: pairwise interleave instead (value_j -> 2j, gate_j -> 2j+1)
     int src_i0 = 0, src_I = 0;                 // copy only source channels [src_i0, src_i0 + src_I) (src_I = 0: all I of them)
+    int dst_f32 = 0;                           // fp32 engine: dst is float [rows][Kdst]
 };
 void launch_repack(const LaunchCtx& ctx, const RepackArgs& a);
 
@@ -168,7 +185,8 @@ struct StepArgs {
     int nhist = 0;
     float lms_c[4] = {0};
     float next_input_scale = 1.0f;          // next step's scale_model_input factor (1/sqrt(sigma^2+1) or 1)
-    half_t* next_input = nullptr;           // fp16 NHWC [N][h*w][Cpad] for the next UNet call (or null)
+    half_t* next_input = nullptr;           // fp16 (fp32 engine: float) NHWC [N][h*w][Cpad] for the next UNet call (or null)
+    int next_input_f32 = 0;
     int Cpad = 64;
     float* eps_out = nullptr;               // optional f32 [B,4,h,w] tap: CFG-combined model output
 };

@@ -68,10 +68,11 @@ DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std
     SDE_REQUIRE(kh == kw && (kh == 1 || kh == 3), SDE_ERR_MODEL, "only 1x1 and 3x3 kernels are supported: " + names[0]);
     const int Ipad = cin_pad > 0 ? cin_pad : I;
     SDE_REQUIRE(Ipad >= I, SDE_ERR_MODEL, "cin_pad smaller than Cin for " + names[0]);
+    if (ctx.f32) geglu = false;   // fp32 engine: no fused GEGLU epilogue, rows stay in file order
     L.taps = kh * kw; L.Cin = Ipad; L.K = L.taps * Ipad; L.N = N; L.Npad = gemm_npad(N); L.geglu = geglu;
     // wide GEGLU projections run on the 256x320 kernel, which wants value/gate of a column in one lane: pairwise interleave
     L.geglu_pair = geglu && N % 320 == 0 && L.K % 64 == 0 && L.taps == 1;
-    const size_t wbytes = (size_t)L.Npad * L.K * sizeof(half_t);
+    const size_t wbytes = (size_t)L.Npad * L.K * ctx.esize();
     L.W = (half_t*)dmalloc(wbytes);
     HIP_CHECK(hipMemsetAsync(L.W, 0, wbytes, ctx.stream));
     int row0 = 0;
@@ -89,7 +90,7 @@ DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std
         r.O = (int)(b.t->dims.size() == 4 ? b.t->dims[0] : b.out_dim());
         r.I = I; r.KH = kh; r.KW = kw; r.in_out = b.in_out ? 1 : 0;
         r.dst = L.W; r.dst_row0 = row0; r.Ipad = Ipad; r.i0 = 0; r.Kdst = L.K;
-        r.geglu_half = geglu ? r.O / 2 : 0; r.geglu_pair = L.geglu_pair ? 1 : 0;
+        r.geglu_half = geglu ? r.O / 2 : 0; r.geglu_pair = L.geglu_pair ? 1 : 0; r.dst_f32 = ctx.f32 ? 1 : 0;
         if (geglu) SDE_REQUIRE(names.size() == 1 && (r.O / 2) % 16 == 0, SDE_ERR_MODEL, "GEGLU projection width must be a multiple of 32");
         launch_repack(ctx, r);
         // the host->device copy of pageable memory may still be reading `staging` asynchronously only on the device side;
@@ -109,6 +110,7 @@ DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std
 DevLinear WeightBuilder::linear_dup(const std::string& name, const std::vector<std::string>& bias_names, int i0, int n)
 {
     DevLinear L;
+    if (ctx.f32) return L;   // fp32 engine: no split-fp16 operands
     const BoundTensor& b = get(name);
     const auto& d = b.t->dims;
     SDE_REQUIRE(d.size() == 2 || (d.size() == 4 && d[2] == 1 && d[3] == 1), SDE_ERR_MODEL, "linear_dup: " + name + " is not a 1x1 / Linear weight");
@@ -145,6 +147,10 @@ namespace {
 
 // NHWC activation [NB*H*W][C]; lo != null: split fp16, value = hi + lo (kernels.h), lo has hi's layout
 struct Tn { half_t* hi = nullptr; half_t* lo = nullptr; };
+
+// p + off ELEMENTS (2 or 4 bytes each, LaunchCtx::esize)
+inline half_t* at(const Exec& ex, half_t* p, size_t off) { return (half_t*)((char*)p + off * ex.ctx.esize()); }
+inline const half_t* at(const Exec& ex, const half_t* p, size_t off) { return (const half_t*)((const char*)p + off * ex.ctx.esize()); }
 
 void run_gemm(Exec& ex, GemmArgs& g)
 {
@@ -214,27 +220,27 @@ Tn resnet(Exec& ex, const ResnetW& r, Tn x0, int c0, Tn x1, int c1, int NB, int 
     const bool sp = ex.split(H * W);
     SDE_REQUIRE(cin == r.cin, SDE_ERR_MODEL, "resnet: input channel mismatch");
     Tn out;
-    out.hi = ex.arena->get<half_t>((size_t)M * r.cout);
-    if (sp) out.lo = ex.arena->get<half_t>((size_t)M * r.cout);
+    out.hi = ex.arena->act((size_t)M * r.cout);
+    if (sp) out.lo = ex.arena->act((size_t)M * r.cout);
     const size_t mk = ex.arena->mark();
-    half_t* hn = ex.arena->get<half_t>((size_t)M * cin);
+    half_t* hn = ex.arena->act((size_t)M * cin);
     groupnorm(ex, r.n1, x0.hi, c0, x1.hi, c1, NB, H * W, eps, true, hn, x0.lo, x1.lo);
-    half_t* h1 = ex.arena->get<half_t>((size_t)M * r.cout);
+    half_t* h1 = ex.arena->act((size_t)M * r.cout);
     conv3x3(ex, r.conv1, hn, cin, NB, H, W, 1, 0, h1, r.cout, r.has_temb ? tbias + r.temb_off : r.conv1.bias, nullptr, 0);
-    half_t* hn2 = ex.arena->get<half_t>((size_t)M * r.cout);
+    half_t* hn2 = ex.arena->act((size_t)M * r.cout);
     groupnorm(ex, r.n2, h1, r.cout, nullptr, 0, NB, H * W, eps, true, hn2);
     Tn sc = x0;
     if (r.has_shortcut) {
-        sc.hi = ex.arena->get<half_t>((size_t)M * r.cout);
-        sc.lo = sp ? ex.arena->get<half_t>((size_t)M * r.cout) : nullptr;
+        sc.hi = ex.arena->act((size_t)M * r.cout);
+        sc.lo = sp ? ex.arena->act((size_t)M * r.cout) : nullptr;
         if (sp && r.has_sc2 && x0.lo && !x1.hi) {
             // split-fp16 operand: K = [x.hi | x.lo] against [W | W]
             linear(ex, r.shortcut_a2, x0.hi, c0, M, sc.hi, r.cout, nullptr, 0, x0.lo, c0, c0, c0, nullptr, sc.lo);
         } else if (sp && r.has_sc2 && x0.lo && x1.lo && c0 == r.sc_c0) {
             // concat input: W_h [h.hi | h.lo] (no bias) chained into W_s [s.hi | s.lo] + bias as a split-fp16 residual
             Tn part;
-            part.hi = ex.arena->get<half_t>((size_t)M * r.cout);
-            part.lo = ex.arena->get<half_t>((size_t)M * r.cout);
+            part.hi = ex.arena->act((size_t)M * r.cout);
+            part.lo = ex.arena->act((size_t)M * r.cout);
             linear(ex, r.shortcut_a2, x0.hi, c0, M, part.hi, r.cout, nullptr, 0, x0.lo, c0, c0, c0, nullptr, part.lo);
             linear(ex, r.shortcut_b2, x1.hi, c1, M, sc.hi, r.cout, part.hi, r.cout, x1.lo, c1, c1, c1, part.lo, sc.lo);
         } else
@@ -260,41 +266,46 @@ Tn transformer(Exec& ex, const TransformerW& t, Tn x, int NB, int H, int W, cons
 {
     const int C = t.C, HW = H * W, M = NB * HW, d = C / t.heads;
     Tn out;
-    out.hi = ex.arena->get<half_t>((size_t)M * C);
-    if (ex.split(HW)) out.lo = ex.arena->get<half_t>((size_t)M * C);
+    out.hi = ex.arena->act((size_t)M * C);
+    if (ex.split(HW)) out.lo = ex.arena->act((size_t)M * C);
     const size_t mk = ex.arena->mark();
-    half_t* n = ex.arena->get<half_t>((size_t)M * C);
+    half_t* n = ex.arena->act((size_t)M * C);
     groupnorm(ex, t.gn, x.hi, C, nullptr, 0, NB, HW, 1e-6f, false, n, x.lo);
     // The block's residual stream x0 -> x0 + attn1 -> .. + attn2 -> .. + ff is carried as an fp32 SUM and rounded to fp16 once, at
     // the end (proj_out reads it as an MFMA operand).  The branch outputs y0..y3 are plain fp16 GEMM outputs; each LayerNorm forms
     // the sum it normalises in fp32.  Rounding the stream after every residual add (three more roundings per block, 48 per UNet call)
     // put the CFG-combined prediction at g = 7.5 over the 1e-2 bar at batch 32 / 227 text tokens.
-    half_t* y0 = ex.arena->get<half_t>((size_t)M * C);
+    half_t* y0 = ex.arena->act((size_t)M * C);
     linear(ex, t.proj_in, n, C, M, y0, C);
     // self-attention
     layernorm(ex, t.ln1, y0, n, M);
-    half_t* qkv = ex.arena->get<half_t>((size_t)M * 3 * C);
+    half_t* qkv = ex.arena->act((size_t)M * 3 * C);
     linear(ex, t.qkv, n, C, M, qkv, 3 * C);
-    half_t* ao = ex.arena->get<half_t>((size_t)M * C);
-    attention(ex, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, ao, C, NB, t.heads, HW, HW, d);
-    half_t* y1 = ex.arena->get<half_t>((size_t)M * C);
+    half_t* ao = ex.arena->act((size_t)M * C);
+    attention(ex, qkv, 3 * C, at(ex, qkv, C), 3 * C, at(ex, qkv, 2 * C), 3 * C, ao, C, NB, t.heads, HW, HW, d);
+    half_t* y1 = ex.arena->act((size_t)M * C);
     linear(ex, t.out1, ao, C, M, y1, C);
     // cross-attention (K/V of the text tokens come from the per-run cache)
     float* s1 = ex.arena->get<float>((size_t)M * C);          // s1 = y0 + y1 (fp32)
     if (!ex.dry()) launch_layernorm_sum(ex.ctx, nullptr, y0, y1, s1, n, M, C, t.ln2.gamma, t.ln2.beta, 1e-5f);
     half_t* q = qkv;  // reuse
     linear(ex, t.q2, n, C, M, q, C);
-    attention(ex, q, C, kv, 2 * C, kv + C, 2 * C, ao, C, NB, t.heads, HW, S, d);
+    attention(ex, q, C, kv, 2 * C, at(ex, kv, C), 2 * C, ao, C, NB, t.heads, HW, S, d);
     half_t* y2 = y0;  // y0 is folded into s1
     linear(ex, t.out2, ao, C, M, y2, C);
     // GEGLU feed-forward
     if (!ex.dry()) launch_layernorm_sum(ex.ctx, s1, y2, nullptr, nullptr, n, M, C, t.ln3.gamma, t.ln3.beta, 1e-5f);
-    half_t* g = ex.arena->get<half_t>((size_t)M * 4 * C);
-    linear(ex, t.ff1, n, C, M, g, 4 * C);
+    half_t* g = ex.arena->act((size_t)M * 4 * C);
+    if (ex.ctx.f32) {   // fp32 engine: plain projection, then the GEGLU product as its own kernel
+        half_t* y8 = ex.arena->act((size_t)M * 8 * C);
+        linear(ex, t.ff1, n, C, M, y8, 8 * C);
+        if (!ex.dry()) f32_launch_geglu(ex.ctx, y8, g, M, 4 * C, t.ff1.gelu_tanh ? 1 : 0);
+    } else
+        linear(ex, t.ff1, n, C, M, g, 4 * C);
     half_t* y3 = y1;  // y1 is folded into s1
     linear(ex, t.ff2, g, 4 * C, M, y3, C);
     half_t* h1 = n;   // the normalised copy is dead: h1 = half(s1 + y2 + y3)
-    half_t* h1lo = (out.lo && t.proj_out2.W) ? ex.arena->get<half_t>((size_t)M * C) : nullptr;   // proj_out reads [h1 | h1lo] against [W | W]
+    half_t* h1lo = (out.lo && t.proj_out2.W) ? ex.arena->act((size_t)M * C) : nullptr;   // proj_out reads [h1 | h1lo] against [W | W]
     if (!ex.dry()) launch_sum_round(ex.ctx, s1, y2, y3, h1, h1lo, (int64_t)M * C);
     if (h1lo) linear(ex, t.proj_out2, h1, C, M, out.hi, C, x.hi, C, h1lo, C, C, C, x.lo, out.lo);
     else linear(ex, t.proj_out, h1, C, M, out.hi, C, x.hi, C, nullptr, 0, 0, 0, x.lo, out.lo);
@@ -417,7 +428,7 @@ void UNetModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b, 
     // shortcut weights for split-fp16 operands (model.h): replay the skip-connection stack to learn each concat's split point
     {
         auto dup = [&](ResnetW& r, const std::string& p, int c0) {
-            if (!r.has_shortcut || c0 % 64 || (r.cin - c0) % 64) return;
+            if (b.ctx.f32 || !r.has_shortcut || c0 % 64 || (r.cin - c0) % 64) return;
             const std::string wn = p + ".conv_shortcut.weight", bn = p + ".conv_shortcut.bias";
             if (c0 == r.cin) r.shortcut_a2 = b.linear_dup(wn, {bn}, 0, c0);
             else { r.shortcut_a2 = b.linear_dup(wn, {}, 0, c0); r.shortcut_b2 = b.linear_dup(wn, {bn}, c0, r.cin - c0); }
@@ -498,8 +509,8 @@ void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, c
     int H = h, W = w;
     auto trunk = [&](int Hx, int Wx, int Cx) {
         Tn t;
-        t.hi = ar.get<half_t>((size_t)N * Hx * Wx * Cx);
-        if (ex.split(Hx * Wx)) t.lo = ar.get<half_t>((size_t)N * Hx * Wx * Cx);
+        t.hi = ar.act((size_t)N * Hx * Wx * Cx);
+        if (ex.split(Hx * Wx)) t.lo = ar.act((size_t)N * Hx * Wx * Cx);
         return t;
     };
     Tn cur = trunk(H, W, boc[0]);
@@ -547,7 +558,7 @@ void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, c
         }
     }
     // 6. head
-    half_t* hn = ar.get<half_t>((size_t)N * H * W * C);
+    half_t* hn = ar.act((size_t)N * H * W * C);
     groupnorm(ex, norm_out, cur.hi, C, nullptr, 0, N, H * W, eps, true, hn, cur.lo);
     conv3x3(ex, conv_out, hn, C, N, H, W, 1, 0, nullptr, 0, conv_out.bias, nullptr, 0, EPI_NCHW_F32, out_nchw);
 }
@@ -600,33 +611,33 @@ void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, in
     int H = h, W = w;
     const int M0 = B * H * W;
     // post_quant_conv (1x1) writes into a zero-padded 64-channel buffer so conv_in can read 64-wide K chunks
-    half_t* z = ar.get<half_t>((size_t)M0 * kInPad);
-    if (!ex.dry()) HIP_CHECK(hipMemsetAsync(z, 0, (size_t)M0 * kInPad * sizeof(half_t), ex.ctx.stream));
+    half_t* z = ar.act((size_t)M0 * kInPad);
+    if (!ex.dry()) HIP_CHECK(hipMemsetAsync(z, 0, (size_t)M0 * kInPad * ex.ctx.esize(), ex.ctx.stream));
     linear(ex, post_quant, x_packed, kInPad, M0, z, kInPad);
     int C = conv_in.N;
-    half_t* cur = ar.get<half_t>((size_t)M0 * C);
+    half_t* cur = ar.act((size_t)M0 * C);
     conv3x3(ex, conv_in, z, kInPad, B, H, W, 1, 0, cur, C, conv_in.bias, nullptr, 0);
     cur = resnet(ex, mid_res0, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi;
     {   // AttentionBlock: single head over H*W tokens
         const int S = H * W, M = B * S;
-        half_t* o = ar.get<half_t>((size_t)M * C);
+        half_t* o = ar.act((size_t)M * C);
         const size_t mk = ar.mark();
-        half_t* n = ar.get<half_t>((size_t)M * C);
+        half_t* n = ar.act((size_t)M * C);
         groupnorm(ex, mid_att.gn, cur, C, nullptr, 0, B, S, eps, false, n);
-        half_t* ao = ar.get<half_t>((size_t)M * C);
-        if (C <= 160 && C % 8 == 0) {
-            half_t* qkv = ar.get<half_t>((size_t)M * 3 * C);
+        half_t* ao = ar.act((size_t)M * C);
+        if (ex.ctx.f32 || (C <= 160 && C % 8 == 0)) {   // (the fp32 engine's attention kernel takes any head width)
+            half_t* qkv = ar.act((size_t)M * 3 * C);
             linear(ex, mid_att.qkv, n, C, M, qkv, 3 * C);
-            attention(ex, qkv, 3 * C, qkv + C, 3 * C, qkv + 2 * C, 3 * C, ao, C, B, 1, S, S, C);
+            attention(ex, qkv, 3 * C, at(ex, qkv, C), 3 * C, at(ex, qkv, 2 * C), 3 * C, ao, C, B, 1, S, S, C);
         } else {
             // wide single head (C = 512): scores via batched GEMMs + row softmax (34 GFLOP / 512^2 image, 1.4 % of the decoder)
             // token counts that are not a multiple of 64 (image sizes that are not a multiple of 64): score rows and V^T rows are
             // pitched to Sp with zero padding, so the P.V product still runs whole 64-wide K chunks
             const int Spad = gemm_npad(S), Sp = round_up(S, 64);
-            half_t* q = ar.get<half_t>((size_t)M * C);
-            half_t* k = ar.get<half_t>((size_t)B * Spad * C);
-            half_t* vT = ar.get<half_t>((size_t)B * gemm_npad(C) * Sp);
-            half_t* sc = ar.get<half_t>((size_t)B * S * Sp);
+            half_t* q = ar.act((size_t)M * C);
+            half_t* k = ar.act((size_t)B * Spad * C);
+            half_t* vT = ar.act((size_t)B * gemm_npad(C) * Sp);
+            half_t* sc = ar.act((size_t)B * S * Sp);
             if (!ex.dry() && Spad != S) HIP_CHECK(hipMemsetAsync(k, 0, (size_t)B * Spad * C * sizeof(half_t), ex.ctx.stream));
             if (!ex.dry() && (gemm_npad(C) != C || Sp != S)) HIP_CHECK(hipMemsetAsync(vT, 0, (size_t)B * gemm_npad(C) * Sp * sizeof(half_t), ex.ctx.stream));
             linear(ex, mid_att.q, n, C, M, q, C);
@@ -662,12 +673,12 @@ void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, in
     for (int i = 0; i < n_levels; ++i) {
         for (auto& r : up[i].res) { cur = resnet(ex, r, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi; C = r.cout; }
         if (up[i].has_up) {
-            half_t* u = ar.get<half_t>((size_t)B * 4 * H * W * C);
+            half_t* u = ar.act((size_t)B * 4 * H * W * C);
             conv3x3(ex, up[i].up, cur, C, B, H, W, 1, 1, u, C, up[i].up.bias, nullptr, 0);
             cur = u; H *= 2; W *= 2;
         }
     }
-    half_t* hn = ar.get<half_t>((size_t)B * H * W * C);
+    half_t* hn = ar.act((size_t)B * H * W * C);
     groupnorm(ex, norm_out, cur, C, nullptr, 0, B, H * W, eps, true, hn);
     conv3x3(ex, conv_out, hn, C, B, H, W, 1, 0, nullptr, 0, conv_out.bias, nullptr, 0, epi, out);
 }

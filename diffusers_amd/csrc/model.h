@@ -22,6 +22,9 @@ struct Arena {
         return base + a;
     }
     template <typename T> T* get(size_t n) { return (T*)alloc(n * sizeof(T)); }
+    // n ACTIVATION elements: fp16 in the default engine, floats in the fp32 engine (LaunchCtx::f32); the pointer type stays half_t*
+    size_t act_bytes = 2;
+    half_t* act(size_t n) { return (half_t*)alloc(n * act_bytes); }
     size_t mark() const { return off; }
     void release(size_t m) { off = m; }
 };

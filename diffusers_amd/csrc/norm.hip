@@ -270,6 +270,7 @@ size_t groupnorm_ws_floats(int NB, int C, int HW)
 void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
 {
     const int C = a.C0 + a.C1;
+    if (ctx.f32) { f32_launch_groupnorm(ctx, a); return; }
     SDE_REQUIRE(C % 8 == 0 && a.C0 % 8 == 0 && C % a.groups == 0 && a.groups <= 64, SDE_ERR_INVALID_ARGUMENT,
                 "groupnorm: C must be a multiple of 8 and of the group count");
     int TPP, OPT, PR, ppc, nchunks;
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* X, half_t*
 
 void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows, int C, const float* gamma, const float* beta, float eps)
 {
+    if (ctx.f32) { f32_launch_layernorm_sum(ctx, nullptr, X, nullptr, nullptr, Y, rows, C, gamma, beta, eps); return; }
     SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
     char nm_l[48] = "layernorm";
     if (getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"))) snprintf(nm_l, sizeof(nm_l), "ln M%d C%d", rows, C);
@@ -486,8 +488,9 @@ __global__ __launch_bounds__(256) void layernorm_sum_kernel(const float* S32, co
 void launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows, int C,
                           const float* gamma, const float* beta, float eps)
 {
-    SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
     SDE_REQUIRE(S32 || A || B, SDE_ERR_INVALID_ARGUMENT, "layernorm_sum: no input");
+    if (ctx.f32) { f32_launch_layernorm_sum(ctx, S32, A, B, S32_out, Y, rows, C, gamma, beta, eps); return; }
+    SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
     ProfScope ps(ctx, "layernorm_sum", 0, (double)rows * C * ((S32 ? 4.0 : 0.0) + (A ? 2.0 : 0.0) + (B ? 2.0 : 0.0) + (S32_out ? 4.0 : 0.0) + 2.0));
     const int noct = cdiv(C / 8, 64);
     const dim3 block(256);
@@ -523,6 +526,7 @@ __global__ void sum_round_kernel(const float* S32, const half_t* A, const half_t
 }
 void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, half_t* Ylo, int64_t n)
 {
+    if (ctx.f32) { SDE_REQUIRE(!Ylo && S32 && A && B, SDE_ERR_INVALID_ARGUMENT, "sum_round: bad arguments"); f32_launch_sum_round(ctx, S32, A, B, Y, n); return; }
     SDE_REQUIRE(n % 8 == 0 && S32 && A && B, SDE_ERR_INVALID_ARGUMENT, "sum_round: bad arguments");
     ProfScope ps(ctx, "residual_sum_round", 0, (Ylo ? 12.0 : 10.0) * n);
     hipLaunchKernelGGL(sum_round_kernel, dim3((unsigned)std::min<long long>(cdiv64(n / 8, 256), 8192)), dim3(256), 0, ctx.stream, S32, A, B, Y,

@@ -26,6 +26,7 @@ from .schedulers import DiffusionScheduler
 class StableDiffusionOptions:
     """pipelines/stable_diffusion/mod.rs:35-38 — here the only device choice is the MI355X ordinal."""
     device_id: int = 0
+    dtype: str = "f16"          # engine precision: "f16" (MFMA kernels, benchmarked) or "f32" (the reference's own precision, plain kernels)
     force_naive: bool = False
     num_heads_override: int = 0
 
@@ -38,6 +39,7 @@ class StableDiffusionPipeline:
         o = _lib.EngineOpts()
         L.sde_engine_opts_default(C.byref(o))
         o.device_id = options.device_id
+        o.dtype = {"f16": 0, "bf16": 1, "f32": 2}[options.dtype]
         o.force_naive = int(options.force_naive)
         o.num_heads_override = options.num_heads_override
         o.load_unet, o.load_vae = int(load_unet), int(load_vae)

@@ -46,7 +46,9 @@ typedef enum sde_dtype { SDE_F16 = 0, SDE_BF16 = 1, SDE_F32 = 2 } sde_dtype;
 
 typedef struct sde_engine_opts {
     int device_id;       /* HIP device ordinal (the new "native MI355X(device_id)" DiffusionDevice, lib.rs:81-107) */
-    int dtype;           /* sde_dtype: activation/weight storage inside the engine; I/O is always f32 */
+    int dtype;           /* sde_dtype: activation/weight storage inside the engine; I/O is always f32.  SDE_F16 (default): MFMA kernels,
+                          * fp32 accumulation, the benchmarked path.  SDE_F32: every tensor and every product in fp32 (plain kernels), the
+                          * precision of the reference's own graphs (sd2pyke.py:86,120-125); bar 1e-4.  SDE_BF16: not implemented (refused). */
     int force_naive;     /* 1 = run every contraction on the plain (non-MFMA) kernels (debug / cross-check) */
     int load_unet;       /* 0 skips unet.onnx  (engine then only serves sde_vae_decode) */
     int load_vae;        /* 0 skips vae_decoder.onnx */

@@ -124,6 +124,33 @@ def test_sd15_batch_invariance_and_determinism(sd15):
     assert rel_l2(part, full[1:3]) < 2e-3   # tile shapes change with the batch, so fp32 summation order may differ
 
 
+def test_sd15_unet_forward_f32_engine():
+    """The fp32 engine at full SD v1.5 geometry: bar 1e-4 (north_star), one forward at batch 2, S = 77."""
+    import time
+    from diffusers_amd.pipeline import StableDiffusionOptions, StableDiffusionPipeline
+    from oracle import model_dir, unet_ref
+    assert os.path.exists(os.path.join(MODEL_DIR, ".complete"))      # written by the module fixture of the tests above
+    pipe = StableDiffusionPipeline(MODEL_DIR, StableDiffusionOptions(dtype="f32"), load_vae=False)
+    try:
+        uw, ucfg = model_dir.load_unet(MODEL_DIR)
+        uw = {k: torch.from_numpy(v) for k, v in uw.items()}
+        rng = np.random.default_rng(3232)
+        x = rng.standard_normal((2, 4, 64, 64)).astype(np.float32)
+        ehs = (rng.standard_normal((2, 77, 768)) * 0.5).astype(np.float32)
+        with torch.no_grad():
+            ref = unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), 500.0, torch.from_numpy(ehs)).numpy()
+        t0 = time.time()
+        got = pipe.unet(x, 500.0, ehs)
+        dt = time.time() - t0
+        err = rel_l2(got, ref)
+        if os.environ.get("SDE_PARITY_LOG"):
+            with open(os.environ["SDE_PARITY_LOG"], "a") as f:
+                f.write(f"f32 engine SD1.5 unet batch 2: rel-L2 {err:.3e}, {dt * 1e3:.0f} ms\n")
+        assert err < 1e-4, err
+    finally:
+        pipe.close()
+
+
 # ---------------------------------------------------------------------------------------------- the benchmarked dispatch
 def test_sd15_unet_forward_batch16(sd15):
     """bench.py's UNet call: batch 16 (B = 8 prompts under CFG), where launch_gemm picks other kernels and split factors than
