@@ -99,16 +99,21 @@ def cpu_baseline(model_dir, seconds_budget=60.0):
             "s_per_image": s_per_image, "unet_s_per_call": t_unet, "unet_it_per_s": 1.0 / t_unet}
 
 
-# engine profiler class -> HIP kernel symbol(s) in a rocprofv3 kernel trace
+# engine profiler class -> the HIP kernel symbol a rocprofv3 kernel trace shows for it.  Several classes can share one symbol (the
+# plain and the GEGLU linears both run gemm_big_kernel<false, false, 5, 0>): the roofline object is computed PER SYMBOL, so that it
+# can be checked line by line against `rocprofv3 --kernel-trace --stats` (profiles/*kernel_stats*.csv).
 ROCPROF_SYMBOL = {
     "conv3x3_mfma_256x320": "gemm_big_kernel<true, UPS, 5, 0>", "conv3x3_mfma_256x256": "gemm_big_kernel<true, UPS, 4, 0>",
-    "gemm_mfma_256x320": "gemm_big_kernel<false, false, 5, 0> (shared with gemm_geglu_mfma_256x320)",
-    "gemm_geglu_mfma_256x320": "gemm_big_kernel<false, false, 5, 0> (shared with gemm_mfma_256x320)",
+    "gemm_mfma_256x320": "gemm_big_kernel<false, false, 5, 0>", "gemm_geglu_mfma_256x320": "gemm_big_kernel<false, false, 5, 0>",
     "gemm_mfma_256x256": "gemm_big_kernel<false, false, 4, 0>",
     "conv3x3_mfma_256x160": "gemm_midl_kernel<true, UPS>", "gemm_mfma_256x160": "gemm_mid_kernel<false, false, 0>",
     "conv3x3_mfma": "gemm_mfma_kernel<BM, BN, true>", "gemm_mfma": "gemm_mfma_kernel<BM, BN, false>",
     "splitk_reduce": "splitk_reduce_kernel",
 }
+
+
+def rocprof_symbol(cls):
+    return ROCPROF_SYMBOL.get(cls) or re.sub(r"^attn_mfma<(\d+),(\d+)>$", r"attn_mfma_kernel<\1, \2, ONES, FOLD>", cls)
 
 
 def spawn_ranks(n, argv):
@@ -335,30 +340,33 @@ def main():
                                      share=round(s["total_ms"] / tot, 4),
                                      tflops=round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1) if s["flops"] and s["total_ms"] else None,
                                      gbs=round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1) if s["bytes"] and s["total_ms"] else None))
-        dom = max(stats, key=lambda s: s["total_ms"])
-        # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the
-        # figure comes from the committed rocprofv3 --pmc passes over this same workload (profiles/r1_pmc_traffic.json)
+        # dominant kernel = the rocprof symbol with the largest summed time (classes that share a symbol are merged)
+        by_sym = {}
+        for st in stats:
+            g = by_sym.setdefault(rocprof_symbol(st["name"]), dict(classes=[], total_ms=0.0, flops=0.0, bytes=0.0, launches=0))
+            g["classes"].append(st["name"]); g["total_ms"] += st["total_ms"]; g["flops"] += st["flops"]; g["bytes"] += st["bytes"]
+            g["launches"] += st["launches"]
+        sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["total_ms"])
+        # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure comes from the
+        # committed rocprofv3 --pmc passes over this same workload (profiles/r2_pmc_traffic.json, FETCH_SIZE / WRITE_SIZE in separate runs)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
-            for key, v in pmc.items():
-                if dom["name"] in key.replace("(", "+").split("+"):
-                    traffic = round((v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"]) * 1e6)
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["symbols"]
+            v = pmc.get(sym)
+            if v:
+                traffic = round((v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"]) * 1e6)
         except Exception:
             traffic = None
+        common = {"kernel": "+".join(dom["classes"]), "rocprof_symbol": sym, "traffic": traffic, "launches": dom["launches"],
+                  "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2), "share_of_gpu_time": round(dom["total_ms"] / tot, 4),
+                  "algorithmic_bytes_per_launch": round(dom["bytes"] / dom["launches"]), "profiled_step_ms": round(rp.total_ms, 2)}
         if dom["flops"] > 0:
             ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
-            # the HIP kernel symbol(s) behind the class, as `rocprofv3 --kernel-trace --stats` prints them (profiles/*kernel_stats*.csv)
-            sym = ROCPROF_SYMBOL.get(dom["name"]) or re.sub(r"^attn_mfma<(\d+),(\d+)>$", r"attn_mfma_kernel<\1, \2, ONES, FOLD>", dom["name"])
-            roof = {"kernel": dom["name"], "rocprof_symbol": sym, "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_TFLOPS_F16, 4), "traffic": traffic, "launches": dom["launches"],
-                    "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2),
-                    "flop_per_launch": dom["flops"] / dom["launches"], "profiled_step_ms": round(rp.total_ms, 2)}
+            roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
+                    "flop_per_launch": dom["flops"] / dom["launches"], **common}
         else:
             ach = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
-            roof = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": traffic, "launches": dom["launches"],
-                    "avg_launch_us": round(dom["total_ms"] / dom["launches"] * 1e3, 2)}
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), **common}
 
     value = units / elapsed
     strong = args.prompts > 0

@@ -7,6 +7,8 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
 A="--steps 1 --warmup 0 --denoise-steps 2 --no-cpu-baseline"
+# counters are collected on plain launches (SDE_GRAPH=0: the same kernels, one dispatch each, without the hipGraph replay)
+export SDE_GRAPH=${SDE_GRAPH_PROFILE:-0}
 O=gpurun_out
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_v3 -o k -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/prof_v3_bench.log 2>&1
 echo stats-done

@@ -44,6 +44,24 @@ def kernel_class(name: str) -> str:
     return base
 
 
+def symbol_key(name: str) -> str:
+    """The kernel symbol as bench.py's ROCPROF_SYMBOL table spells it (template arguments that only select a loader variant folded)."""
+    m = re.match(r"(?:void )?(\w+)(?:<(.*)>)?", name)
+    base, targs = (m.group(1), m.group(2) or "") if m else (name, "")
+    t = [a.strip() for a in targs.split(",")] if targs else []
+    if base == "gemm_big_kernel" and len(t) >= 4:
+        return f"gemm_big_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, {t[3]}>"
+    if base == "gemm_midl_kernel" and len(t) >= 2:
+        return f"gemm_midl_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}>"
+    if base == "gemm_mid_kernel" and len(t) >= 3:
+        return f"gemm_mid_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}>"
+    if base == "gemm_mfma_kernel" and len(t) >= 3:
+        return f"gemm_mfma_kernel<BM, BN, {t[2]}>"
+    if base == "attn_mfma_kernel" and len(t) >= 2:
+        return f"attn_mfma_kernel<{t[0]}, {t[1]}, ONES, FOLD>"
+    return base
+
+
 def engine_class(name: str, dur_ns: float, split: dict) -> str:
     """Engine-profiler class name (what bench.py's kernel table uses)."""
     k = kernel_class(name)
@@ -58,6 +76,7 @@ def engine_class(name: str, dur_ns: float, split: dict) -> str:
 def traffic(fetch_csv: str, write_csv: str, out_path: str, source: str):
     """profiles/r1_pmc_traffic.json: HBM-side bytes per launch per engine kernel class from two separate --pmc passes."""
     res = defaultdict(lambda: defaultdict(float))
+    sym = defaultdict(lambda: defaultdict(float))
     for path, counter, key in ((fetch_csv, "FETCH_SIZE", "fetch_kb"), (write_csv, "WRITE_SIZE", "write_kb")):
         rows = [r for r in csv.DictReader(open(path, newline="")) if r["Counter_Name"] == counter]
         split = {}
@@ -70,7 +89,16 @@ def traffic(fetch_csv: str, write_csv: str, out_path: str, source: str):
             e = res[engine_class(r["Kernel_Name"], d, split)]
             e[key] += float(r["Counter_Value"])
             e[key + "_n"] += 1
-    out = {"source": source, "kernels": {}}
+            g = sym[symbol_key(r["Kernel_Name"])]
+            g[key] += float(r["Counter_Value"])
+            g[key + "_n"] += 1
+    out = {"source": source, "kernels": {}, "symbols": {}}
+    for k, e in sorted(sym.items(), key=lambda kv: -(kv[1]["fetch_kb"] + kv[1]["write_kb"])):
+        if e.get("fetch_kb_n") and e.get("write_kb_n"):
+            f = e["fetch_kb"] * 1024 / e["fetch_kb_n"] / 1e6
+            out["symbols"][k] = {"launches": int(e["fetch_kb_n"]), "fetch_MB_per_launch_raw": round(f, 2),
+                                 "fetch_MB_per_launch_corrected_x2": round(2 * f, 2),
+                                 "write_MB_per_launch": round(e["write_kb"] * 1024 / e["write_kb_n"] / 1e6, 2)}
     for k, e in sorted(res.items(), key=lambda kv: -(kv[1]["fetch_kb"] + kv[1]["write_kb"])):
         if not e.get("fetch_kb_n") or not e.get("write_kb_n"):
             continue
