@@ -30,7 +30,7 @@ def main():
     reps = 4
     only = os.environ.get("MB_ONLY", "")
     convs = [c for c in CONVS if not only or (only == "small" and NB * c[0] * c[0] <= 4096) or (only == "big" and NB * c[0] * c[0] > 4096)
-             or (only == "c64" and c[0] == 64 and c[3] == 3 and c[4] == 1) or (only == "k64" and c[1] == 64) or (only == "wide" and c[3] == 1 and c[2] >= 960) or (only == "c32" and c[0] == 32 and c[3] == 3 and c[5] == 0)]
+             or (only == "c64" and c[0] == 64 and c[3] == 3 and c[4] == 1) or (only == "k64" and c[1] == 64) or (only == "wide" and c[3] == 1 and c[2] >= 960) or (only == "lin64" and c[0] == 64 and c[3] == 1 and c[1] >= 320) or (only == "c32" and c[0] == 32 and c[3] == 3 and c[5] == 0)]
     for (H, Cin, Cout, k, stride, ups) in convs:
         x = rng.standard_normal((NB, H, H, Cin), dtype=np.float32)
         w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
