@@ -363,7 +363,10 @@ def main():
         if dom["flops"] > 0:
             ach = dom["flops"] / (dom["total_ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS_F16, 4),
-                    "flop_per_launch": dom["flops"] / dom["launches"], **common}
+                    "flop_per_launch": dom["flops"] / dom["launches"],
+                    # the same launches against the other roof: a class of short-K linears sits near the ridge (2500 / 8 = 312 flop/B)
+                    "flop_per_byte": round(dom["flops"] / dom["bytes"], 1) if dom["bytes"] else None,
+                    "hbm_frac": round(dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if dom["bytes"] else None, **common}
         else:
             ach = dom["bytes"] / (dom["total_ms"] * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), **common}

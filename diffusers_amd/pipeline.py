@@ -117,10 +117,12 @@ class StableDiffusionPipeline:
     def profile_get(self) -> List[dict]:
         L = _lib.lib()
         n = C.c_int()
-        arr = (_lib.KernelStat * 64)()
-        _lib.check(L.sde_profile_get(self._h, arr, 64, C.byref(n)))
+        _lib.check(L.sde_profile_get(self._h, None, 0, C.byref(n)))          # class count first (per-shape tables exceed any fixed size)
+        cap = max(n.value, 1)
+        arr = (_lib.KernelStat * cap)()
+        _lib.check(L.sde_profile_get(self._h, arr, cap, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), total_ms=float(arr[i].total_ms),
-                     flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(min(n.value, 64))]
+                     flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(min(n.value, cap))]
 
 
 CB_NONE, CB_PROGRESS, CB_LATENTS, CB_DECODED, CB_APPROXIMATE = range(5)
