@@ -33,7 +33,10 @@ constexpr int RSRC_FLAGS = 0x00020000;
 // VAR: 0 in the product.  Diagnostic builds (-DSDE_DIAG, wrong results, timing only): bit0 = no loads in the main loop,
 // bit1 = no fragment reads, bit2 = no barriers.
 // NT = 16-column tiles per wave: 5 -> 256x320 block tile (UNet widths 320/640/1280), 4 -> 256x256 (VAE widths 256/512).
-template <bool CONV, bool UPS, int NT, int VAR = 0>
+// LO: the split-fp16 epilogue (residual and / or result as hi + lo pairs, kernels.h).  A separate instance because its extra live
+// registers (second residual set, low halves) push the 256-VGPR kernel into scratch spills inside the latency-critical epilogue:
+// compiled into the plain instance it cost the 64x64-level linears 25-30 % (27.9 -> 35.3 us at M=65536, N=K=320).
+template <bool CONV, bool UPS, int NT, int VAR = 0, bool LO = false>
 __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -334,14 +337,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
         }
         const half_t* R = p.R ? p.R + zR : nullptr;
-        const half_t* Rlo = (p.R && p.Rlo) ? p.Rlo + zR : nullptr;   // split-fp16 residual / result (kernels.h)
+        const half_t* Rlo = (LO && p.R && p.Rlo) ? p.Rlo + zR : nullptr;   // split-fp16 residual / result (kernels.h)
         half_t* D = p.D + zD;
-        half_t* Dlo = p.Dlo ? p.Dlo + zD : nullptr;
+        half_t* Dlo = (LO && p.Dlo) ? p.Dlo + zD : nullptr;
         const bool rvec_ok = R && (p.ldr & 7) == 0;
 #pragma unroll
         for (int ms = 0; ms < 4; ++ms) {
             // residual chunks of these 32 rows, in flight while the accumulators go through LDS
-            half8 rr[NI], rl[NI];
+            half8 rr[NI], rl[LO ? NI : 1];
             if (R) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
@@ -349,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
                     const int m = min(m0 + wr * 128 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
                     if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
                     else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
-                    if (Rlo) {
+                    if constexpr (LO) if (Rlo) {
                         if (rvec_ok) rl[i] = *(const half8*)(Rlo + (long long)m * p.ldr + n);
                         else for (int e = 0; e < 8; ++e) rl[i][e] = Rlo[(long long)m * p.ldr + n + e];
                     }
@@ -378,17 +381,17 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     float x = R ? f[e] + (float)rr[i][e] : f[e];
-                    if (Rlo) x += (float)rl[i][e];
+                    if constexpr (LO) if (Rlo) x += (float)rl[i][e];
                     v[e] = (half_t)x;
-                    vl[e] = (half_t)(x - (float)v[e]);
+                    if constexpr (LO) vl[e] = (half_t)(x - (float)v[e]);
                 }
                 if (m < p.M && n < p.N) {
                     if (vec_ok && n + 8 <= p.N) {
                         *(half8*)(D + (long long)m * p.ldd + n) = v;
-                        if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;
+                        if constexpr (LO) if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;
                     } else for (int e = 0; e < 8 && n + e < p.N; ++e) {
                         D[(long long)m * p.ldd + n + e] = v[e];
-                        if (Dlo) Dlo[(long long)m * p.ldd + n + e] = vl[e];
+                        if constexpr (LO) if (Dlo) Dlo[(long long)m * p.ldd + n + e] = vl[e];
                     }
                 }
             }
@@ -409,6 +412,7 @@ bool gemm_big_supported(const GemmArgs& a)
     if (!gemm_mfma_supported(c)) return false;
     if (!gemm_big_bn(a) || (a.epi != EPI_STD && a.epi != EPI_GEGLU_PAIR) || (a.N & 3)) return false;   // other epilogues stay on gemm.hip's kernel
     if (a.epi == EPI_GEGLU_PAIR && (a.ldd & 1)) return false;
+    if ((a.Rlo || a.Dlo) && gemm_big_bn(a) != 320) return false;   // the split-fp16 epilogue instance exists for the 256x320 tile only
     // 32-bit byte offsets inside a 2 GiB descriptor window
     const long long rowsA = a.taps == 9 ? (long long)(a.M / (a.Ho * a.Wo)) * (a.ups ? ((a.Hi + 1) / 2) * ((a.Wi + 1) / 2) : a.Hi * a.Wi) : a.M;
     if (rowsA >= (1 << 24) || a.lda0 * 2 >= (1 << 23) || a.lda1 * 2 >= (1 << 23) || a.Wi >= (1 << 16)) return false;
@@ -417,12 +421,20 @@ bool gemm_big_supported(const GemmArgs& a)
     return true;
 }
 
+template <bool CONV, bool UPS, int NT, int VAR = 0, bool LO = false>
+static void launch_big_lo(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
+{
+    auto kern = gemm_big_kernel<CONV, UPS, NT, VAR, LO>;
+    allow_dynamic_lds((const void*)kern, smem_bytes(NT));
+    hipLaunchKernelGGL(kern, grid, dim3(512), smem_bytes(NT), ctx.stream, p);
+}
 template <bool CONV, bool UPS, int NT, int VAR = 0>
 static void launch_big_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
-    auto kern = gemm_big_kernel<CONV, UPS, NT, VAR>;
-    allow_dynamic_lds((const void*)kern, smem_bytes(NT));
-    hipLaunchKernelGGL(kern, grid, dim3(512), smem_bytes(NT), ctx.stream, p);
+    if (p.Rlo || p.Dlo) {
+        if constexpr (VAR == 0 && NT == 5) launch_big_lo<CONV, UPS, NT, 0, true>(ctx, p, grid);   // split-fp16 operands only occur at UNet widths
+        else SDE_REQUIRE(false, SDE_ERR_INVALID_ARGUMENT, "gemm_big: split-fp16 epilogue is built for the 256x320 tile only");
+    } else launch_big_lo<CONV, UPS, NT, VAR, false>(ctx, p, grid);
 }
 
 void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)

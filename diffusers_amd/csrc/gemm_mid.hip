@@ -42,6 +42,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 }  // namespace
 
 // epilogue shared by both kernels: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
+// LO: split-fp16 residual / result (hi + lo pairs); its own instance so the plain epilogue keeps its register budget (gemm_big.hip)
+template <bool LO>
 __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT][MT], int m0, int n0, int ks, int z,
                                              int wid, int wr, int wc, int lane, int fr, int fg)
 {
@@ -74,13 +76,13 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
         for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
     }
     const half_t* R = p.R ? p.R + zR : nullptr;
-    const half_t* Rlo = (p.R && p.Rlo) ? p.Rlo + zR : nullptr;   // split-fp16 residual / result (kernels.h)
+    const half_t* Rlo = (LO && p.R && p.Rlo) ? p.Rlo + zR : nullptr;   // split-fp16 residual / result (kernels.h)
     half_t* D = p.D + zD;
-    half_t* Dlo = p.Dlo ? p.Dlo + zD : nullptr;
+    half_t* Dlo = (LO && p.Dlo) ? p.Dlo + zD : nullptr;
     const bool rvec_ok = R && (p.ldr & 7) == 0;
 #pragma unroll
     for (int ms = 0; ms < 2; ++ms) {
-        half8 rr[NI], rl[NI];
+        half8 rr[NI], rl[LO ? NI : 1];
         if (R) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
@@ -88,7 +90,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
                 const int m = min(m0 + wr * 64 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
                 if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
                 else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
-                if (Rlo) {
+                if constexpr (LO) if (Rlo) {
                     if (rvec_ok) rl[i] = *(const half8*)(Rlo + (long long)m * p.ldr + n);
                     else for (int e = 0; e < 8; ++e) rl[i][e] = Rlo[(long long)m * p.ldr + n + e];
                 }
@@ -117,17 +119,17 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float x = R ? f[e] + (float)rr[i][e] : f[e];
-                if (Rlo) x += (float)rl[i][e];
+                if constexpr (LO) if (Rlo) x += (float)rl[i][e];
                 v[e] = (half_t)x;
-                vl[e] = (half_t)(x - (float)v[e]);
+                if constexpr (LO) vl[e] = (half_t)(x - (float)v[e]);
             }
             if (m < p.M && n < p.N) {
                 if (vec_ok && n + 8 <= p.N) {
                     *(half8*)(D + (long long)m * p.ldd + n) = v;
-                    if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;
+                    if constexpr (LO) if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;
                 } else for (int e = 0; e < 8 && n + e < p.N; ++e) {
                     D[(long long)m * p.ldd + n + e] = v[e];
-                    if (Dlo) Dlo[(long long)m * p.ldd + n + e] = vl[e];
+                    if constexpr (LO) if (Dlo) Dlo[(long long)m * p.ldd + n + e] = vl[e];
                 }
             }
         }
@@ -137,7 +139,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
 }
 
 // staging parts of one K-tile: 0-3 = A rows 64j..64j+63, 4-5 = W rows 0-63 / 64-127, 6 = W rows 128-159 (waves 0-3 only)
-template <bool CONV, bool UPS, int VAR>
+template <bool CONV, bool UPS, int VAR, bool LO = false>
 __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
 {
     static_assert(kMidSched[VAR][0][0] <= 2, "waves 0-3 may stage only their own A rows in L0");
@@ -348,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
 #undef WAIT_PROLOGUE
 #undef ISSUE_L
 
-    mid_epilogue(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
+    mid_epilogue<LO>(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
 }
 
 // ------------------------------------------------------------------------------------------ loader-wave variant
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
 //   I1: A rows 128-255 (waves 4-7 finished reading tile t-1 during I0)                                  4
 //   I2: W rows, first 3 pieces                                                                          3
 //   I3: W rows, last 2 pieces; then wait until only tile t+2's 13 pieces are in flight (tile t+1 has landed)
-template <bool CONV, bool UPS>
+template <bool CONV, bool UPS, bool LO = false>
 __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -533,7 +535,7 @@ __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
 #undef MFMA_ALL
 #undef BAR
 #undef FENCE
-    mid_epilogue(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
+    mid_epilogue<LO>(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -550,6 +552,12 @@ bool gemm_mid_supported(const GemmArgs& a)
 template <bool CONV, bool UPS, int VAR = 0>
 static void launch_mid_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
+    if (VAR == 0 && (p.Rlo || p.Dlo)) {
+        auto kern = gemm_mid_kernel<CONV, UPS, 0, true>;
+        allow_dynamic_lds((const void*)kern, SMEM_BYTES);
+        hipLaunchKernelGGL(kern, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
+        return;
+    }
     auto kern = gemm_mid_kernel<CONV, UPS, VAR>;
     allow_dynamic_lds((const void*)kern, SMEM_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(512), SMEM_BYTES, ctx.stream, p);
@@ -558,6 +566,12 @@ static void launch_mid_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 template <bool CONV, bool UPS>
 static void launch_midl_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 {
+    if (p.Rlo || p.Dlo) {
+        auto kern = gemm_midl_kernel<CONV, UPS, true>;
+        allow_dynamic_lds((const void*)kern, SMEM_BYTES);
+        hipLaunchKernelGGL(kern, grid, dim3(768), SMEM_BYTES, ctx.stream, p);
+        return;
+    }
     auto kern = gemm_midl_kernel<CONV, UPS>;
     allow_dynamic_lds((const void*)kern, SMEM_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(768), SMEM_BYTES, ctx.stream, p);
