@@ -325,10 +325,13 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         }
         return;
     }
-    {   // EPI_STD, 32 rows (two row groups) at a time: fp32 in LDS so the residual is added before the single rounding
+    {   // EPI_STD, 32 rows (two row groups) at a time: fp32 in LDS so the residual is added before the single rounding.
+        // The split-fp16 instance goes 16 rows at a time: its second residual set and low halves would not fit the register file otherwise.
         constexpr int PITCH = WN * 4 + 32;      // LDS row pitch (bytes, fp32)
         constexpr int CH = WN / 8;              // 8-column chunks per row (32 B in LDS, 16 B in memory)
-        constexpr int NI = 32 * CH / 64;        // chunks per lane and step
+        constexpr int RG = LO ? 1 : 2;          // 16-row groups per step
+        constexpr int NCH = RG * 16 * CH;       // chunks per step
+        constexpr int NI = (NCH + 63) / 64;     // chunks per lane and step
         float bv[NT][4];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -342,14 +345,14 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         half_t* Dlo = (LO && p.Dlo) ? p.Dlo + zD : nullptr;
         const bool rvec_ok = R && (p.ldr & 7) == 0;
 #pragma unroll
-        for (int ms = 0; ms < 4; ++ms) {
-            // residual chunks of these 32 rows, in flight while the accumulators go through LDS
+        for (int ms = 0; ms < 8 / RG; ++ms) {
+            // residual chunks of these rows, in flight while the accumulators go through LDS
             half8 rr[NI], rl[LO ? NI : 1];
             if (R) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i) {
-                    const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
-                    const int m = min(m0 + wr * 128 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
+                    const int id = min(lane + 64 * i, NCH - 1), row = id / CH, ch = id - row * CH;
+                    const int m = min(m0 + wr * 128 + ms * (16 * RG) + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
                     if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
                     else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
                     if constexpr (LO) if (Rlo) {
@@ -359,8 +362,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
                 }
             }
 #pragma unroll
-            for (int mq = 0; mq < 2; ++mq) {
-                const int mt = ms * 2 + mq;
+            for (int mq = 0; mq < RG; ++mq) {
+                const int mt = ms * RG + mq;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     floatx4 o;
@@ -373,8 +376,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
-                const int m = m0 + wr * 128 + ms * 32 + row, n = n0 + wc * WN + ch * 8;
+                const int id = lane + 64 * i, idc = min(id, NCH - 1), row = idc / CH, ch = idc - row * CH;
+                const int m = m0 + wr * 128 + ms * (16 * RG) + row, n = n0 + wc * WN + ch * 8;
                 const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
                 const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 half8 v, vl;
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
                     v[e] = (half_t)x;
                     if constexpr (LO) vl[e] = (half_t)(x - (float)v[e]);
                 }
-                if (m < p.M && n < p.N) {
+                if (id < NCH && m < p.M && n < p.N) {
                     if (vec_ok && n + 8 <= p.N) {
                         *(half8*)(D + (long long)m * p.ldd + n) = v;
                         if constexpr (LO) if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;

@@ -42,6 +42,9 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 }  // namespace
 
 // epilogue shared by both kernels: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
+#ifndef MID_RG
+#define MID_RG(LO) ((LO) ? 1 : 2)
+#endif
 // LO: split-fp16 residual / result (hi + lo pairs); its own instance so the plain epilogue keeps its register budget (gemm_big.hip)
 template <bool LO>
 __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT][MT], int m0, int n0, int ks, int z,
@@ -67,7 +70,9 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
     // EPI_STD through the wave's own LDS slice (see gemm_big.hip): fp32 staging, 16-byte row-order stores
     char* const wlds = smem + wid * (SMEM_BYTES / 8);
     const bool vec_ok = (p.ldd & 7) == 0;
-    constexpr int PITCH = WN * 4 + 32, CH = WN / 8, NI = 32 * CH / 64;
+    constexpr int PITCH = WN * 4 + 32, CH = WN / 8;
+    constexpr int RG = MID_RG(LO);          // 16-row groups per step (gemm_big.hip: the split-fp16 instance takes one)
+    constexpr int NCH = RG * 16 * CH, NI = (NCH + 63) / 64;
     float bv[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -81,24 +86,23 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
     half_t* Dlo = (LO && p.Dlo) ? p.Dlo + zD : nullptr;
     const bool rvec_ok = R && (p.ldr & 7) == 0;
 #pragma unroll
-    for (int ms = 0; ms < 2; ++ms) {
+    for (int ms = 0; ms < MT / RG; ++ms) {
         half8 rr[NI], rl[LO ? NI : 1];
         if (R) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
-                const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
-                const int m = min(m0 + wr * 64 + ms * 32 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
-                if (rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
+                const int id = min(lane + 64 * i, NCH - 1), row = id / CH, ch = id - row * CH;
+                const int m = min(m0 + wr * 64 + ms * (16 * RG) + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
+                if (LO || rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
                 else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
                 if constexpr (LO) if (Rlo) {
-                    if (rvec_ok) rl[i] = *(const half8*)(Rlo + (long long)m * p.ldr + n);
-                    else for (int e = 0; e < 8; ++e) rl[i][e] = Rlo[(long long)m * p.ldr + n + e];
+                    rl[i] = *(const half8*)(Rlo + (long long)m * p.ldr + n);
                 }
             }
         }
 #pragma unroll
-        for (int mq = 0; mq < 2; ++mq) {
-            const int mt = ms * 2 + mq;
+        for (int mq = 0; mq < RG; ++mq) {
+            const int mt = ms * RG + mq;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 floatx4 o;
@@ -111,8 +115,8 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int id = lane + 64 * i, row = id / CH, ch = id - row * CH;
-            const int m = m0 + wr * 64 + ms * 32 + row, n = n0 + wc * WN + ch * 8;
+            const int id = lane + 64 * i, idc = min(id, NCH - 1), row = idc / CH, ch = idc - row * CH;
+            const int m = m0 + wr * 64 + ms * (16 * RG) + row, n = n0 + wc * WN + ch * 8;
             const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
             const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             half8 v, vl;
@@ -123,8 +127,8 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
                 v[e] = (half_t)x;
                 if constexpr (LO) vl[e] = (half_t)(x - (float)v[e]);
             }
-            if (m < p.M && n < p.N) {
-                if (vec_ok && n + 8 <= p.N) {
+            if (id < NCH && m < p.M && n < p.N) {
+                if (LO || (vec_ok && n + 8 <= p.N)) {   // LO: the host only sends 16-byte aligned rows and N % 8 == 0 here
                     *(half8*)(D + (long long)m * p.ldd + n) = v;
                     if constexpr (LO) if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;
                 } else for (int e = 0; e < 8 && n + e < p.N; ++e) {
@@ -544,6 +548,7 @@ bool gemm_big_supported(const GemmArgs& a);   // gemm_big.hip: shared operand ru
 bool gemm_mid_supported(const GemmArgs& a)
 {
     if (a.epi != EPI_STD || a.Npad % BN || (a.N & 7)) return false;
+    if ((a.Rlo || a.Dlo) && ((a.ldd & 7) || (a.R && (a.ldr & 7)))) return false;   // the split-fp16 epilogue has 16-byte paths only
     GemmArgs c = a;
     c.Npad = 320 * ((a.Npad + 319) / 320);   // reuse the operand / offset-range rules, not the tile-width rule
     return gemm_big_supported(c);
