@@ -20,6 +20,9 @@
 
 #include <algorithm>
 
+#ifndef BIG_RG
+#define BIG_RG(LO) ((LO) ? 1 : 2)
+#endif
 namespace {
 constexpr int BM = 256;
 constexpr int A_BYTES = BM * 128;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         // The split-fp16 instance goes 16 rows at a time: its second residual set and low halves would not fit the register file otherwise.
         constexpr int PITCH = WN * 4 + 32;      // LDS row pitch (bytes, fp32)
         constexpr int CH = WN / 8;              // 8-column chunks per row (32 B in LDS, 16 B in memory)
-        constexpr int RG = LO ? 1 : 2;          // 16-row groups per step
+        constexpr int RG = BIG_RG(LO);          // 16-row groups per step
         constexpr int NCH = RG * 16 * CH;       // chunks per step
         constexpr int NI = (NCH + 63) / 64;     // chunks per lane and step
         float bv[NT][4];
