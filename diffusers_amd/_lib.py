@@ -49,7 +49,7 @@ class Txt2ImgOpts(C.Structure):
                 ("callback", CALLBACK), ("callback_user", C.c_void_p), ("noise_pred_out", C.c_void_p),
                 ("latents_out", C.c_void_p), ("final_latents_out", C.c_void_p),
                 ("cfg_half", C.c_int), ("exchange", EXCHANGE), ("exchange_user", C.c_void_p),
-                ("trace_rows", C.c_int), ("step_noise_rows", C.c_int)]
+                ("trace_rows", C.c_int), ("step_noise_rows", C.c_int), ("start_step", C.c_int)]
 
 
 class RunStats(C.Structure):
@@ -78,6 +78,9 @@ SYMBOLS = {
     "sde_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sde_vae_decode_dev": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sde_vae_decoder_run": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sde_engine_load_vae_encoder": (_i, [_vp, C.c_char_p]),
+    "sde_vae_encoder_run": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "sde_vae_encoder_out_shape": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "sde_approximate_decode": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sde_approximate_decode_noalloc": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sde_sched_cfg_sd_v1": (None, [_i, C.POINTER(SchedCfg)]),

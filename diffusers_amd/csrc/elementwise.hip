@@ -134,6 +134,28 @@ void launch_gemv(const LaunchCtx& ctx, const half_t* W, const float* x, const fl
     HIP_CHECK(hipGetLastError());
 }
 
+// ------------------------------------------------------------------------------------------ VAE posterior sample
+// DiagonalGaussianDistribution.sample() as the exported vae_encoder.onnx computes it (sd2pyke.py:181-187): moments = (mean | logvar)
+// along channels, logvar clamped to [-30, 20], sample = mean + exp(0.5 logvar) * noise; noise == null returns the mean (mode()).
+__global__ void vae_sample_kernel(const float* moments, const float* noise, float* out, int B, int LCHW)
+{
+    const long long total = (long long)B * LCHW;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / LCHW, r = i - b * LCHW;
+        const float mean = moments[b * 2 * LCHW + r];
+        const float logvar = fminf(fmaxf(moments[b * 2 * LCHW + LCHW + r], -30.0f), 20.0f);
+        out[i] = noise ? mean + expf(0.5f * logvar) * noise[i] : mean;
+    }
+}
+void launch_vae_sample(const LaunchCtx& ctx, const float* moments, const float* noise, float* out, int B, int latent_channels, int h, int w)
+{
+    const long long total = (long long)B * latent_channels * h * w;
+    ProfScope ps(ctx, "vae_posterior_sample", 0, 16.0 * total);
+    hipLaunchKernelGGL(vae_sample_kernel, dim3((unsigned)std::min<long long>(cdiv64(total, 256), 4096)), dim3(256), 0, ctx.stream, moments, noise, out, B,
+                       latent_channels * h * w);
+    HIP_CHECK(hipGetLastError());
+}
+
 // ------------------------------------------------------------------------------------------ approximate decode
 // impl_main.rs:385-395: einsum("blxy,lr->bxyr") with a fixed 4x3 matrix, then clamp [0,1] (to_image).
 __global__ void approx_decode_kernel(const float* lat, float* img, int B, int HW)

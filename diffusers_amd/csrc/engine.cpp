@@ -148,6 +148,10 @@ struct sde_engine {
     WeightBuilder wb;
     UNetModel unet;
     VaeDecoderModel vae;
+    VaeEncoderModel vae_enc;
+    bool has_vae_enc = false;
+    std::string model_dir;          // set by sde_engine_create (sde_engine_load_vae_encoder(NULL) resolves the TOML entry against it)
+    long long enc_key = -1; size_t enc_peak = 0;
     bool has_unet = false, has_vae = false;
     Arena arena;
     DevBuf arena_buf, zeros, splitk_ws, kvbuf, ehs_h, ehs_f, x_packed, model_out, latents, noise, images, vae_in, hist[4], scratch_f, taps, rescale_ws;
@@ -452,7 +456,9 @@ sde_status sde_engine_create(const char* model_dir, const sde_engine_opts* opts,
         vp = std::string(model_dir) + "/" + cfg.vae_decoder_path;
     });
     if (st != SDE_OK) return st;
-    return engine_create_impl(up, vp, opts, out);
+    st = engine_create_impl(up, vp, opts, out);
+    if (st == SDE_OK && out && *out) (*out)->model_dir = model_dir;
+    return st;
 }
 
 sde_status sde_engine_create_from_files(const char* unet_onnx, const char* vae_decoder_onnx, const sde_engine_opts* opts, sde_engine** out)
@@ -568,6 +574,82 @@ static sde_status vae_common(sde_engine* e, const float* latents, int B, int h, 
 sde_status sde_vae_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images) { return vae_common(e, latents, B, h, w, images, EPI_IMAGE, false); }
 sde_status sde_vae_decode_dev(sde_engine* e, const float* latents, int B, int h, int w, float* images) { return vae_common(e, latents, B, h, w, images, EPI_IMAGE, true); }
 sde_status sde_vae_decoder_run(sde_engine* e, const float* latents, int B, int h, int w, float* sample) { return vae_common(e, latents, B, h, w, sample, EPI_NCHW_F32, false); }
+
+sde_status sde_engine_load_vae_encoder(sde_engine* e, const char* onnx_path)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e, SDE_ERR_INVALID_ARGUMENT, "null engine");
+        std::string path = onnx_path ? onnx_path : "";
+        if (path.empty()) {
+            SDE_REQUIRE(!e->model_dir.empty(), SDE_ERR_INVALID_ARGUMENT, "no path given and the engine was not created from a model directory");
+            PykeConfig cfg;
+            pyke_config_load(e->model_dir, cfg);
+            SDE_REQUIRE(!cfg.vae_encoder_path.empty(), SDE_ERR_MODEL, "pyke-diffusers.toml names no [vae] encoder");
+            path = e->model_dir + "/" + cfg.vae_encoder_path;
+        }
+        EngineLock lk(e);
+        engine_activate(e);
+        OnnxModel m; WeightMap w;
+        onnx_load(path, m);
+        bind_weights(m, w);
+        e->wb.w = &w; e->wb.params = 0; e->wb.gelu_tanh = false;
+        e->vae_enc = VaeEncoderModel();
+        e->has_vae_enc = false;
+        e->vae_enc.build(m, w, e->wb);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        e->wb.w = nullptr;
+        e->wb.release_staging();
+        e->has_vae_enc = true; e->enc_key = -1;
+    });
+}
+
+sde_status sde_vae_encoder_out_shape(const sde_engine* e, int H, int W, int* latent_channels, int* h, int* w)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && latent_channels && h && w, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(e->has_vae_enc, SDE_ERR_MODEL, "no VAE encoder loaded (sde_engine_load_vae_encoder)");
+        SDE_REQUIRE(H >= e->vae_enc.downscale() && W >= e->vae_enc.downscale(), SDE_ERR_INVALID_ARGUMENT, "image smaller than the encoder's downscale factor");
+        *latent_channels = e->vae_enc.latent_channels;
+        *h = VaeEncoderModel::out_size(H, e->vae_enc.n_levels); *w = VaeEncoderModel::out_size(W, e->vae_enc.n_levels);
+    });
+}
+
+sde_status sde_vae_encoder_run(sde_engine* e, const float* sample, int B, int H, int W, const float* noise, float* latent_sample)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && sample && latent_sample, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(e->has_vae_enc, SDE_ERR_MODEL, "no VAE encoder loaded (sde_engine_load_vae_encoder)");
+        SDE_REQUIRE(B > 0 && H > 0 && W > 0, SDE_ERR_INVALID_ARGUMENT, "empty tensor");
+        const VaeEncoderModel& v = e->vae_enc;
+        SDE_REQUIRE(H >= v.downscale() && W >= v.downscale(), SDE_ERR_INVALID_ARGUMENT, "image smaller than the encoder's downscale factor");
+        EngineLock lk(e);
+        engine_activate(e);
+        const int h = VaeEncoderModel::out_size(H, v.n_levels), w = VaeEncoderModel::out_size(W, v.n_levels), LC = v.latent_channels;
+        const size_t ni = (size_t)B * v.in_channels * H * W, nl = (size_t)B * LC * h * w;
+        // staging: image f32 | noise f32 | moments f32 | sample f32, then the packed fp16 image
+        e->scratch_f.ensure((ni + nl + 2 * nl + nl) * sizeof(float));
+        float* d_img = e->scratch_f.as<float>();
+        float* d_noise = d_img + ni; float* d_mom = d_noise + nl; float* d_out = d_mom + 2 * nl;
+        HIP_CHECK(hipMemcpyAsync(d_img, sample, ni * 4, hipMemcpyHostToDevice, e->stream));
+        if (noise) HIP_CHECK(hipMemcpyAsync(d_noise, noise, nl * 4, hipMemcpyHostToDevice, e->stream));
+        e->vae_in.ensure((size_t)B * H * W * VaeEncoderModel::kInPad * e->ctx.esize());
+        launch_pack_nchw(e->ctx, d_img, e->vae_in.as<half_t>(), B, v.in_channels, H, W, VaeEncoderModel::kInPad, 1.0f);
+        const long long key = ((long long)B << 40) ^ ((long long)H << 20) ^ W;
+        if (key != e->enc_key) {
+            Arena dry; dry.dry = true; dry.act_bytes = e->ctx.esize();
+            Exec dx{e->ctx, &dry};
+            v.forward(dx, nullptr, B, H, W, nullptr);
+            e->enc_peak = dry.peak; e->enc_key = key;
+        }
+        ensure_arena(e, std::max(std::max(e->unet_peak, e->vae_peak), e->enc_peak));
+        e->arena.off = 0; e->arena.peak = 0; e->arena.dry = false; e->arena.act_bytes = e->ctx.esize();
+        Exec ex{e->ctx, &e->arena};
+        v.forward(ex, e->vae_in.as<half_t>(), B, H, W, d_mom);
+        launch_vae_sample(e->ctx, d_mom, noise ? d_noise : nullptr, d_out, B, LC, h, w);
+        HIP_CHECK(hipMemcpyAsync(latent_sample, d_out, nl * 4, hipMemcpyDeviceToHost, e->stream));
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+    });
+}
 
 sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images)
 {
@@ -795,6 +877,9 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
                         "step_noise holds " + std::to_string(rows) + " rows but this scheduler runs " + std::to_string(nt) +
                             " timesteps (set step_noise_rows from sde_scheduler_num_timesteps)");
         }
+        const int i0 = o->start_step;   // image-to-image: the loop starts inside the schedule (sdengine.h)
+        SDE_REQUIRE(i0 >= 0 && i0 < nt, SDE_ERR_INVALID_ARGUMENT, "start_step must lie inside the scheduler's timesteps");
+        SDE_REQUIRE(i0 == 0 || o->init_latents, SDE_ERR_INVALID_ARGUMENT, "start_step > 0 needs init_latents (the noised image latents)");
         long long num_warmup = (long long)nt - (long long)o->steps * 1;  // :270 ; negative == usize wrap-around in release builds
         if (num_warmup < 0) num_warmup = (1LL << 62);
 
@@ -822,7 +907,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             HIP_CHECK(hipMemcpyAsync(d_lat, host_tmp.data(), per * 4, hipMemcpyHostToDevice, st));
             HIP_CHECK(hipStreamSynchronize(st));
         }
-        launch_vec_op(e->ctx, d_lat, nullptr, d_lat, (int64_t)per, 2, sch->init_noise_sigma, 0.f);  // :265
+        if (i0 == 0) launch_vec_op(e->ctx, d_lat, nullptr, d_lat, (int64_t)per, 2, sch->init_noise_sigma, 0.f);  // :265
         for (auto& hb : e->hist) hb.ensure(per * 4, true, st);
         float* hist[4] = {e->hist[0].as<float>(), e->hist[1].as<float>(), e->hist[2].as<float>(), e->hist[3].as<float>()};
         const bool want_taps = o->noise_pred_out != nullptr;
@@ -846,7 +931,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
 
         // first model input: scale_model_input(concat(latents, latents), t0)  (:273-278)
         {
-            float div = sch->input_scale_divisor(ts[0]);
+            float div = sch->input_scale_divisor(ts[(size_t)i0]);
             launch_pack_latents(e->ctx, d_lat, e->x_packed.as<half_t>(), B, (cfg && !half) ? 2 : 1, C, h, w, Cp, 1.0f / div);
         }
         int unet_calls = 0;
@@ -857,10 +942,10 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         } lane_drain{e};
         bool pending_cb = false, stopped = false;   // a payload callback produced at step pending_i, not yet delivered
         int pending_i = 0; float pending_t = 0.f; size_t pending_n = 0;
-        for (int i = 0; i < nt; ++i) {
+        for (int i = i0; i < nt; ++i) {
             const float t = ts[(size_t)i];
             const auto tq0 = std::chrono::steady_clock::now();
-            unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, (const half_t*)(e->ehs_h.as<char>() + half_off * B * S * D * e->ctx.esize()), S, i == 0,
+            unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, (const half_t*)(e->ehs_h.as<char>() + half_off * B * S * D * e->ctx.esize()), S, i == i0,
                      e->model_out.as<float>() + half_off * per);                                             // :283
             enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
             if (pending_cb) {
@@ -1031,8 +1116,12 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3;   // 0 fast, 1 plain, 2 / 3 force the 256x320 / 256x160 kernel
         const int taps = ksize * ksize;
         // upsample: 1 = nearest 2x; 2 = 2x cropped to (2*Hi - 1) x (2*Wi - 1), the UNet's upsample-to-skip-size on odd latents
+        // upsample == 3: not an upsample -- the VAE encoder's downsampler, pad (0,1,0,1) + a pad-0 stride-2 window (GemmArgs::coff = 1)
+        const bool asym = upsample == 3;
+        SDE_REQUIRE(!asym || (ksize == 3 && stride == 2 && Hi >= 2 && Wi >= 2), SDE_ERR_INVALID_ARGUMENT, "asymmetric padding goes with a 3x3 stride-2 conv");
+        if (asym) upsample = 0;
         const int Hv = upsample ? 2 * Hi - (upsample == 2) : Hi, Wv = upsample ? 2 * Wi - (upsample == 2) : Wi;
-        const int Ho = ksize == 3 ? (Hv - 1) / stride + 1 : Hv, Wo = ksize == 3 ? (Wv - 1) / stride + 1 : Wv;
+        const int Ho = asym ? (Hi - 2) / 2 + 1 : (ksize == 3 ? (Hv - 1) / stride + 1 : Hv), Wo = asym ? (Wi - 2) / 2 + 1 : (ksize == 3 ? (Wv - 1) / stride + 1 : Wv);
         const size_t nx = (size_t)NB * Hi * Wi * Cin, nw = (size_t)Cout * Cin * taps, no = (size_t)NB * Ho * Wo * Cout;
         const int Npad = gemm_npad(Cout), K = taps * Cin;
         DevBuf dxf, dxh, dwf, dwh, dbias, doh, dof;
@@ -1048,6 +1137,7 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         launch_repack(ctx, r);
         GemmArgs g;
         g.A0 = dxh.as<half_t>(); g.lda0 = Cin; g.C0 = Cin; g.taps = taps; g.stride = ksize == 3 ? stride : 1; g.ups = ksize == 3 ? (upsample != 0) : 0;
+        g.coff = asym ? 1 : 0;
         g.Hi = Hv; g.Wi = Wv; g.Ho = Ho; g.Wo = Wo; g.M = NB * Ho * Wo; g.N = Cout; g.K = K;
         g.W = dwh.as<half_t>(); g.Npad = Npad; g.bias = bias ? dbias.as<float>() : nullptr; g.D = doh.as<half_t>(); g.ldd = Cout;
         launch_gemm(ctx, g);

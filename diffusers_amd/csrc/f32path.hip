@@ -19,7 +19,7 @@ __device__ __forceinline__ float wsum(float v)
 struct GemmF {
     const float* A0; const float* A1;
     int C0, C1, lda0, lda1;
-    int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws;
+    int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws, coff;
     const float* W; int Npad;
     const float* bias; const float* R; int ldr;
     float* D; float* Df; int ldd; int epi; float alpha;
@@ -40,7 +40,7 @@ __device__ __forceinline__ float a_at(const GemmF& p, const float* A0, const flo
         c = chunk * ck + (rem - tap * ck);
         const int hw = p.Ho * p.Wo;
         const int nb = m / hw, r = m - nb * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
-        const int iy = oy * p.stride - 1 + tap / 3, ix = ox * p.stride - 1 + tap % 3;
+        const int iy = oy * p.stride + p.coff - 1 + tap / 3, ix = ox * p.stride + p.coff - 1 + tap % 3;
         if ((unsigned)iy >= (unsigned)p.Hi || (unsigned)ix >= (unsigned)p.Wi) return 0.f;
         pix = (long long)nb * p.Hs * p.Ws + (long long)(iy >> p.ups) * p.Ws + (ix >> p.ups);
     }
@@ -317,7 +317,7 @@ void f32_launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     SDE_REQUIRE(!a.Rlo && !a.Dlo, SDE_ERR_INVALID_ARGUMENT, "fp32 engine: no split-fp16 tensors");
     GemmF p;
     p.A0 = (const float*)a.A0; p.A1 = (const float*)a.A1; p.C0 = a.C0; p.C1 = a.C1; p.lda0 = a.lda0; p.lda1 = a.lda1;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.taps = a.taps; p.stride = a.stride; p.ups = a.ups; p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.taps = a.taps; p.stride = a.stride; p.coff = a.coff; p.ups = a.ups; p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
     p.Hs = a.ups ? (a.Hi + 1) / 2 : a.Hi; p.Ws = a.ups ? (a.Wi + 1) / 2 : a.Wi;
     p.W = (const float*)a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = (const float*)a.R; p.ldr = a.ldr;
     p.D = (float*)a.D; p.Df = a.Df; p.ldd = a.ldd; p.epi = a.epi; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR;

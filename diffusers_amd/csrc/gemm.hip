@@ -68,8 +68,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(GemmDev p)
             int nb = m / hw, rem = m - nb * hw;
             int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_base[i] = nb * p.Hs * p.Ws;
-            a_y[i] = oy * p.stride - 1;
-            a_x[i] = ox * p.stride - 1;
+            a_y[i] = oy * p.stride + p.coff - 1;
+            a_x[i] = ox * p.stride + p.coff - 1;
         } else {
             a_base[i] = m; a_y[i] = 0; a_x[i] = 0;
         }
@@ -233,7 +233,7 @@ __global__ void gemm_naive_kernel(GemmDev p)
         for (int tap = 0; tap < p.taps; ++tap) {
             long long pix; bool ok = true;
             if (p.taps == 9) {
-                int iy = oy * p.stride - 1 + tap / 3, ix = ox * p.stride - 1 + tap % 3;
+                int iy = oy * p.stride + p.coff - 1 + tap / 3, ix = ox * p.stride + p.coff - 1 + tap % 3;
                 ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
                 pix = (long long)nb * p.Hs * p.Ws + (iy >> p.ups) * p.Ws + (ix >> p.ups);
             } else pix = m;
@@ -277,7 +277,7 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
 {
     GemmDev p;
     p.A0 = a.A0; p.A1 = a.A1; p.C0 = a.C0; p.C1 = a.C1; p.lda0 = a.lda0; p.lda1 = a.lda1;
-    p.M = a.M; p.N = a.N; p.K = a.K; p.taps = a.taps; p.stride = a.stride; p.ups = a.ups;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.taps = a.taps; p.stride = a.stride; p.coff = a.coff; p.ups = a.ups;
     p.Hi = a.Hi; p.Wi = a.Wi; p.Ho = a.Ho; p.Wo = a.Wo;
     p.Hs = a.ups ? (a.Hi + 1) / 2 : a.Hi; p.Ws = a.ups ? (a.Wi + 1) / 2 : a.Wi;   // ups: virtual (Hi x Wi) = nearest-2x of (Hs x Ws), cropped when odd
     p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.Rlo = a.Rlo; p.Dlo = a.Dlo; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             const int hw = p.Ho * p.Wo;
             const int nb = m / hw, rem = m - nb * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const int cy = oy * p.stride, cx = ox * p.stride;   // window centre in the (virtual) input
+            const int cy = oy * p.stride + p.coff, cx = ox * p.stride + p.coff;   // window centre in the (virtual) input
             unsigned mask = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {

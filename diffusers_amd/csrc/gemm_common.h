@@ -13,7 +13,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));
 struct GemmDev {
     const half_t* A0; const half_t* A1;
     int C0, C1, lda0, lda1;
-    int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws;
+    int M, N, K, taps, stride, ups, Hi, Wi, Ho, Wo, Hs, Ws, coff;
     const half_t* W; int Npad;
     const float* bias; const half_t* R; const half_t* Rlo; half_t* Dlo; int ldr;
     half_t* D; float* Df; int ldd; int epi; int gelu_tanh; float alpha;

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
             const int hw = p.Ho * p.Wo;
             const int nb = m / hw, rem = m - nb * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const int cy = oy * p.stride, cx = ox * p.stride;
+            const int cy = oy * p.stride + p.coff, cx = ox * p.stride + p.coff;
             unsigned mask = 0;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
                 const int hw = p.Ho * p.Wo;
                 const int nb = m / hw, rem = m - nb * hw;
                 const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-                const int cy = oy * p.stride, cx = ox * p.stride;
+                const int cy = oy * p.stride + p.coff, cx = ox * p.stride + p.coff;
                 unsigned mask = 0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {

@@ -68,6 +68,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;     // K = taps * (C0 + C1)
     int taps = 1;                // 1 (linear / 1x1) or 9 (3x3, pad 1)
     int stride = 1;              // conv stride (1 or 2)
+    int coff = 0;                // window centre = o*stride + coff: 0 = symmetric pad 1; 1 = the VAE encoder's pad (0,1,0,1) + stride-2, pad-0 conv
     int ups = 0;                 // 1: the source tensor is (Hi/2 x Wi/2), nearest-upsampled 2x on the fly
     int Hi = 0, Wi = 0;          // (virtual) input height/width; Ho, Wo output
     int Ho = 0, Wo = 0;
@@ -149,6 +150,9 @@ void launch_gemv(const LaunchCtx& ctx, const half_t* W, const float* x, const fl
                  bool pre_silu, bool post_silu);
 // approximate_decode_latents: latents NCHW f32 [B,4,h,w] -> NHWC f32 [B,h,w,3] clamped
 void launch_approx_decode(const LaunchCtx& ctx, const float* lat, float* img, int B, int h, int w);
+
+// VAE posterior: moments f32 NCHW [B, 2*LC, h, w] (mean | logvar) -> out f32 [B, LC, h, w] = mean + exp(0.5 clamp(logvar)) * noise (noise null: mean)
+void launch_vae_sample(const LaunchCtx& ctx, const float* moments, const float* noise, float* out, int B, int latent_channels, int h, int w);
 
 // weight repack: src (f32 or f16) -> dst fp16 [rows][Kdst], see loader for the index maps
 struct RepackArgs {

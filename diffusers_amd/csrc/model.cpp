@@ -178,14 +178,16 @@ void linear(Exec& ex, const DevLinear& L, const half_t* A, int lda, int M, half_
 // sizes floor(y * H / Hu) == y >> 1 for every y < Hu, i.e. the 2x upsample cropped by one row / column.
 void conv3x3(Exec& ex, const DevLinear& L, const half_t* A, int C, int NB, int H, int W, int stride, int ups, half_t* D, int ldd,
              const float* bias, const half_t* R, int ldr, int epi = EPI_STD, float* Df = nullptr, int Hu = 0, int Wu = 0,
-             const half_t* Rlo = nullptr, half_t* Dlo = nullptr)
+             const half_t* Rlo = nullptr, half_t* Dlo = nullptr, int coff = 0)
 {
     GemmArgs g;
     g.A0 = A; g.lda0 = C; g.C0 = C;
-    g.taps = 9; g.stride = stride; g.ups = ups;
+    g.taps = 9; g.stride = stride; g.ups = ups; g.coff = coff;
+    SDE_REQUIRE(coff == 0 || (coff == 1 && stride == 2 && !ups && H >= 2 && W >= 2), SDE_ERR_INVALID_ARGUMENT, "conv3x3: asymmetric padding goes with stride 2");
     g.Hi = ups ? (Hu ? Hu : 2 * H) : H; g.Wi = ups ? (Wu ? Wu : 2 * W) : W;
     SDE_REQUIRE(!ups || ((g.Hi + 1) / 2 == H && (g.Wi + 1) / 2 == W), SDE_ERR_INVALID_ARGUMENT, "conv3x3: upsample target must be 2x or 2x - 1");
     g.Ho = (g.Hi - 1) / stride + 1; g.Wo = (g.Wi - 1) / stride + 1;
+    if (coff) { g.Ho = (g.Hi - 2) / 2 + 1; g.Wo = (g.Wi - 2) / 2 + 1; }   // pad (0,1,0,1), then a pad-0 stride-2 window
     g.M = NB * g.Ho * g.Wo; g.N = L.N; g.K = L.K;
     g.W = L.W; g.Npad = L.Npad; g.bias = bias; g.R = R; g.ldr = ldr; g.D = D; g.Df = Df; g.ldd = ldd; g.epi = epi; g.Rlo = Rlo; g.Dlo = Dlo;
     SDE_REQUIRE(L.taps == 9 && L.Cin == C, SDE_ERR_MODEL, "conv3x3: channel mismatch");
@@ -564,6 +566,76 @@ void UNetModel::forward(Exec& ex, const half_t* x_packed, int N, int h, int w, c
 }
 
 // ------------------------------------------------------------------------------------------ VAE decoder
+// AttentionBlock of the AutoencoderKL mid block (decoder and encoder): GroupNorm, single head over H*W tokens, proj + residual
+static half_t* vae_attention(Exec& ex, const VaeAttnW& mid_att, half_t* cur, int C, int B, int H, int W, float eps)
+{
+    Arena& ar = *ex.arena;
+    const int S = H * W, M = B * S;
+    half_t* o = ar.act((size_t)M * C);
+    const size_t mk = ar.mark();
+    half_t* n = ar.act((size_t)M * C);
+    groupnorm(ex, mid_att.gn, cur, C, nullptr, 0, B, S, eps, false, n);
+    half_t* ao = ar.act((size_t)M * C);
+    if (ex.ctx.f32 || (C <= 160 && C % 8 == 0)) {   // (the fp32 engine's attention kernel takes any head width)
+        half_t* qkv = ar.act((size_t)M * 3 * C);
+        linear(ex, mid_att.qkv, n, C, M, qkv, 3 * C);
+        attention(ex, qkv, 3 * C, at(ex, qkv, C), 3 * C, at(ex, qkv, 2 * C), 3 * C, ao, C, B, 1, S, S, C);
+    } else {
+        // wide single head (C = 512): scores via batched GEMMs + row softmax (34 GFLOP / 512^2 image, 1.4 % of the decoder)
+        // token counts that are not a multiple of 64 (image sizes that are not a multiple of 64): score rows and V^T rows are
+        // pitched to Sp with zero padding, so the P.V product still runs whole 64-wide K chunks
+        const int Spad = gemm_npad(S), Sp = round_up(S, 64);
+        half_t* q = ar.act((size_t)M * C);
+        half_t* k = ar.act((size_t)B * Spad * C);
+        half_t* vT = ar.act((size_t)B * gemm_npad(C) * Sp);
+        half_t* sc = ar.act((size_t)B * S * Sp);
+        if (!ex.dry() && Spad != S) HIP_CHECK(hipMemsetAsync(k, 0, (size_t)B * Spad * C * sizeof(half_t), ex.ctx.stream));
+        if (!ex.dry() && (gemm_npad(C) != C || Sp != S)) HIP_CHECK(hipMemsetAsync(vT, 0, (size_t)B * gemm_npad(C) * Sp * sizeof(half_t), ex.ctx.stream));
+        linear(ex, mid_att.q, n, C, M, q, C);
+        for (int bi = 0; bi < B; ++bi) {   // K rows are laid out per image with Spad rows so they can serve as a GEMM "W"
+            linear(ex, mid_att.k, n + (size_t)bi * S * C, C, S, k + (size_t)bi * Spad * C, C);
+            GemmArgs g;   // V^T[c][s]
+            g.A0 = n + (size_t)bi * S * C; g.lda0 = C; g.C0 = C; g.M = S; g.N = C; g.K = C; g.taps = 1;
+            g.W = mid_att.v.W; g.Npad = mid_att.v.Npad; g.bias = mid_att.v.bias; g.D = vT + (size_t)bi * gemm_npad(C) * Sp; g.ldd = Sp;
+            g.epi = EPI_TRANS;
+            run_gemm(ex, g);
+        }
+        {
+            GemmArgs g;   // scores[b] = q[b] k[b]^T / sqrt(C)
+            g.A0 = q; g.lda0 = C; g.C0 = C; g.M = S; g.N = S; g.K = C; g.taps = 1;
+            g.W = k; g.Npad = Spad; g.D = sc; g.ldd = Sp; g.alpha = 1.0f / sqrtf((float)C);
+            g.batch = B; g.sA = (long long)S * C; g.sW = (long long)Spad * C; g.sD = (long long)S * Sp;
+            run_gemm(ex, g);
+        }
+        if (!ex.dry()) launch_softmax_rows(ex.ctx, sc, (int64_t)B * S, S, Sp);
+        {
+            GemmArgs g;   // ao[b] = P[b] V[b]
+            g.A0 = sc; g.lda0 = Sp; g.C0 = Sp; g.M = S; g.N = C; g.K = Sp; g.taps = 1;
+            g.W = vT; g.Npad = gemm_npad(C); g.D = ao; g.ldd = C;
+            g.batch = B; g.sA = (long long)S * Sp; g.sW = (long long)gemm_npad(C) * Sp; g.sD = (long long)S * C;
+            run_gemm(ex, g);
+        }
+    }
+    linear(ex, mid_att.proj, ao, C, M, o, C, cur, C);
+    ar.release(mk);
+    return o;
+}
+
+static void build_vae_attention(WeightBuilder& b, const std::string& a, VaeAttnW& att)
+{
+    att.gn = b.norm(a + ".group_norm");
+    att.q = b.linear({a + ".query.weight"}, {a + ".query.bias"});
+    att.k = b.linear({a + ".key.weight"}, {a + ".key.bias"});
+    att.v = b.linear({a + ".value.weight"}, {a + ".value.bias"});
+    {   // merged copy for the flash path (narrow VAEs); not counted twice
+        const int64_t before = b.params;
+        att.qkv = b.linear({a + ".query.weight", a + ".key.weight", a + ".value.weight"}, {a + ".query.bias", a + ".key.bias", a + ".value.bias"});
+        b.params = before;
+    }
+    att.proj = b.linear({a + ".proj_attn.weight"}, {a + ".proj_attn.bias"});
+    att.C = att.q.N;
+}
+
 void VaeDecoderModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b)
 {
     (void)m;
@@ -577,18 +649,7 @@ void VaeDecoderModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilde
     post_quant = b.linear({"post_quant_conv.weight"}, {"post_quant_conv.bias"}, kInPad);
     conv_in = b.linear({"decoder.conv_in.weight"}, {"decoder.conv_in.bias"}, kInPad);
     mid_res0 = build_resnet(b, "decoder.mid_block.resnets.0", false);
-    const std::string a = "decoder.mid_block.attentions.0";
-    mid_att.gn = b.norm(a + ".group_norm");
-    mid_att.q = b.linear({a + ".query.weight"}, {a + ".query.bias"});
-    mid_att.k = b.linear({a + ".key.weight"}, {a + ".key.bias"});
-    mid_att.v = b.linear({a + ".value.weight"}, {a + ".value.bias"});
-    {   // merged copy for the flash path (narrow VAEs); not counted twice
-        const int64_t before = b.params;
-        mid_att.qkv = b.linear({a + ".query.weight", a + ".key.weight", a + ".value.weight"}, {a + ".query.bias", a + ".key.bias", a + ".value.bias"});
-        b.params = before;
-    }
-    mid_att.proj = b.linear({a + ".proj_attn.weight"}, {a + ".proj_attn.bias"});
-    mid_att.C = mid_att.q.N;
+    build_vae_attention(b, "decoder.mid_block.attentions.0", mid_att);
     mid_res1 = build_resnet(b, "decoder.mid_block.resnets.1", false);
     up.assign(n_levels, UpBlock());
     boc.clear();
@@ -618,57 +679,7 @@ void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, in
     half_t* cur = ar.act((size_t)M0 * C);
     conv3x3(ex, conv_in, z, kInPad, B, H, W, 1, 0, cur, C, conv_in.bias, nullptr, 0);
     cur = resnet(ex, mid_res0, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi;
-    {   // AttentionBlock: single head over H*W tokens
-        const int S = H * W, M = B * S;
-        half_t* o = ar.act((size_t)M * C);
-        const size_t mk = ar.mark();
-        half_t* n = ar.act((size_t)M * C);
-        groupnorm(ex, mid_att.gn, cur, C, nullptr, 0, B, S, eps, false, n);
-        half_t* ao = ar.act((size_t)M * C);
-        if (ex.ctx.f32 || (C <= 160 && C % 8 == 0)) {   // (the fp32 engine's attention kernel takes any head width)
-            half_t* qkv = ar.act((size_t)M * 3 * C);
-            linear(ex, mid_att.qkv, n, C, M, qkv, 3 * C);
-            attention(ex, qkv, 3 * C, at(ex, qkv, C), 3 * C, at(ex, qkv, 2 * C), 3 * C, ao, C, B, 1, S, S, C);
-        } else {
-            // wide single head (C = 512): scores via batched GEMMs + row softmax (34 GFLOP / 512^2 image, 1.4 % of the decoder)
-            // token counts that are not a multiple of 64 (image sizes that are not a multiple of 64): score rows and V^T rows are
-            // pitched to Sp with zero padding, so the P.V product still runs whole 64-wide K chunks
-            const int Spad = gemm_npad(S), Sp = round_up(S, 64);
-            half_t* q = ar.act((size_t)M * C);
-            half_t* k = ar.act((size_t)B * Spad * C);
-            half_t* vT = ar.act((size_t)B * gemm_npad(C) * Sp);
-            half_t* sc = ar.act((size_t)B * S * Sp);
-            if (!ex.dry() && Spad != S) HIP_CHECK(hipMemsetAsync(k, 0, (size_t)B * Spad * C * sizeof(half_t), ex.ctx.stream));
-            if (!ex.dry() && (gemm_npad(C) != C || Sp != S)) HIP_CHECK(hipMemsetAsync(vT, 0, (size_t)B * gemm_npad(C) * Sp * sizeof(half_t), ex.ctx.stream));
-            linear(ex, mid_att.q, n, C, M, q, C);
-            for (int bi = 0; bi < B; ++bi) {   // K rows are laid out per image with Spad rows so they can serve as a GEMM "W"
-                linear(ex, mid_att.k, n + (size_t)bi * S * C, C, S, k + (size_t)bi * Spad * C, C);
-                GemmArgs g;   // V^T[c][s]
-                g.A0 = n + (size_t)bi * S * C; g.lda0 = C; g.C0 = C; g.M = S; g.N = C; g.K = C; g.taps = 1;
-                g.W = mid_att.v.W; g.Npad = mid_att.v.Npad; g.bias = mid_att.v.bias; g.D = vT + (size_t)bi * gemm_npad(C) * Sp; g.ldd = Sp;
-                g.epi = EPI_TRANS;
-                run_gemm(ex, g);
-            }
-            {
-                GemmArgs g;   // scores[b] = q[b] k[b]^T / sqrt(C)
-                g.A0 = q; g.lda0 = C; g.C0 = C; g.M = S; g.N = S; g.K = C; g.taps = 1;
-                g.W = k; g.Npad = Spad; g.D = sc; g.ldd = Sp; g.alpha = 1.0f / sqrtf((float)C);
-                g.batch = B; g.sA = (long long)S * C; g.sW = (long long)Spad * C; g.sD = (long long)S * Sp;
-                run_gemm(ex, g);
-            }
-            if (!ex.dry()) launch_softmax_rows(ex.ctx, sc, (int64_t)B * S, S, Sp);
-            {
-                GemmArgs g;   // ao[b] = P[b] V[b]
-                g.A0 = sc; g.lda0 = Sp; g.C0 = Sp; g.M = S; g.N = C; g.K = Sp; g.taps = 1;
-                g.W = vT; g.Npad = gemm_npad(C); g.D = ao; g.ldd = C;
-                g.batch = B; g.sA = (long long)S * Sp; g.sW = (long long)gemm_npad(C) * Sp; g.sD = (long long)S * C;
-                run_gemm(ex, g);
-            }
-        }
-        linear(ex, mid_att.proj, ao, C, M, o, C, cur, C);
-        ar.release(mk);
-        cur = o;
-    }
+    cur = vae_attention(ex, mid_att, cur, C, B, H, W, eps);
     cur = resnet(ex, mid_res1, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi;
     for (int i = 0; i < n_levels; ++i) {
         for (auto& r : up[i].res) { cur = resnet(ex, r, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi; C = r.cout; }
@@ -681,4 +692,71 @@ void VaeDecoderModel::forward(Exec& ex, const half_t* x_packed, int B, int h, in
     half_t* hn = ar.act((size_t)B * H * W * C);
     groupnorm(ex, norm_out, cur, C, nullptr, 0, B, H * W, eps, true, hn);
     conv3x3(ex, conv_out, hn, C, B, H, W, 1, 0, nullptr, 0, conv_out.bias, nullptr, 0, epi, out);
+}
+
+// ------------------------------------------------------------------------------------------ VAE encoder
+void VaeEncoderModel::build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b)
+{
+    (void)m;
+    n_levels = count_prefix(w, "encoder.down_blocks.", ".resnets.0.conv1.weight");
+    SDE_REQUIRE(n_levels >= 1 && n_levels <= 8, SDE_ERR_MODEL, "vae encoder: cannot find encoder.down_blocks.*.resnets.0.conv1.weight");
+    layers_per_block = count_prefix(w, "encoder.down_blocks.0.resnets.", ".conv1.weight");
+    in_channels = (int)b.get("encoder.conv_in.weight").t->dims[1];
+    const int moments = (int)b.get("quant_conv.weight").t->dims[0];
+    SDE_REQUIRE(moments % 2 == 0 && moments <= kInPad && in_channels <= kInPad, SDE_ERR_MODEL, "vae encoder: unexpected channel counts");
+    latent_channels = moments / 2;
+    conv_in = b.linear({"encoder.conv_in.weight"}, {"encoder.conv_in.bias"}, kInPad);
+    down.assign(n_levels, DownBlock());
+    boc.clear();
+    for (int i = 0; i < n_levels; ++i) {
+        const std::string p = "encoder.down_blocks." + std::to_string(i);
+        for (int j = 0; j < layers_per_block; ++j) down[i].res.push_back(build_resnet(b, p + ".resnets." + std::to_string(j), false));
+        boc.push_back(down[i].res[0].cout);
+        down[i].has_down = w.count(p + ".downsamplers.0.conv.weight") != 0;
+        if (down[i].has_down) down[i].down = b.linear({p + ".downsamplers.0.conv.weight"}, {p + ".downsamplers.0.conv.bias"});
+    }
+    mid_res0 = build_resnet(b, "encoder.mid_block.resnets.0", false);
+    build_vae_attention(b, "encoder.mid_block.attentions.0", mid_att);
+    mid_res1 = build_resnet(b, "encoder.mid_block.resnets.1", false);
+    norm_out = b.norm("encoder.conv_norm_out");
+    conv_out = b.linear({"encoder.conv_out.weight"}, {"encoder.conv_out.bias"});
+    quant = b.linear({"quant_conv.weight"}, {"quant_conv.bias"}, kInPad);
+    n_params = b.params;
+}
+
+void VaeEncoderModel::forward(Exec& ex, const half_t* x_packed, int B, int H, int W, float* moments) const
+{
+    Arena& ar = *ex.arena;
+    const float eps = 1e-6f;
+    int C = conv_in.N;
+    half_t* cur = ar.act((size_t)B * H * W * C);
+    conv3x3(ex, conv_in, x_packed, kInPad, B, H, W, 1, 0, cur, C, conv_in.bias, nullptr, 0);
+    for (int i = 0; i < n_levels; ++i) {
+        for (auto& r : down[i].res) { cur = resnet(ex, r, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi; C = r.cout; }
+        if (down[i].has_down) {
+            // Downsample2D(padding = 0): F.pad(x, (0, 1, 0, 1)) then a 3x3 stride-2 conv without padding -- the window of output
+            // (oy, ox) is centred on input (2 oy + 1, 2 ox + 1)
+            SDE_REQUIRE(H >= 2 && W >= 2, SDE_ERR_INVALID_ARGUMENT, "vae encoder: image too small for this many levels");
+            const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
+            half_t* d = ar.act((size_t)B * Ho * Wo * C);
+            conv3x3(ex, down[i].down, cur, C, B, H, W, 2, 0, d, C, down[i].down.bias, nullptr, 0, EPI_STD, nullptr, 0, 0, nullptr, nullptr, 1);
+            cur = d; H = Ho; W = Wo;
+        }
+    }
+    cur = resnet(ex, mid_res0, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi;
+    cur = vae_attention(ex, mid_att, cur, C, B, H, W, eps);
+    cur = resnet(ex, mid_res1, Tn{cur, nullptr}, C, Tn(), 0, B, H, W, eps, nullptr).hi;
+    const int M = B * H * W;
+    half_t* hn = ar.act((size_t)M * C);
+    groupnorm(ex, norm_out, cur, C, nullptr, 0, B, H * W, eps, true, hn);
+    // conv_out writes its 2*latent channels into a zero-padded 64-channel buffer so quant_conv (1x1) reads one 64-wide K chunk
+    half_t* mo = ar.act((size_t)M * kInPad);
+    if (!ex.dry()) HIP_CHECK(hipMemsetAsync(mo, 0, (size_t)M * kInPad * ex.ctx.esize(), ex.ctx.stream));
+    conv3x3(ex, conv_out, hn, C, B, H, W, 1, 0, mo, kInPad, conv_out.bias, nullptr, 0);
+    GemmArgs g;
+    g.A0 = mo; g.lda0 = kInPad; g.C0 = kInPad; g.M = M; g.N = quant.N; g.K = quant.K; g.taps = 1;
+    g.Hi = g.Ho = H; g.Wi = g.Wo = W;
+    g.W = quant.W; g.Npad = quant.Npad; g.bias = quant.bias; g.Df = moments; g.epi = EPI_NCHW_F32;
+    SDE_REQUIRE(quant.K == kInPad, SDE_ERR_MODEL, "vae encoder: quant_conv is not a 1x1 convolution");
+    run_gemm(ex, g);
 }

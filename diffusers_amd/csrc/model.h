@@ -119,6 +119,27 @@ struct VaeDecoderModel {
     static constexpr int kInPad = 64;
 };
 
+// AutoencoderKL encoder + quant_conv (vae_encoder.onnx, sd2pyke.py:181-187,325-346): the session the reference opens
+// (impl_main.rs:58,140-150) and never runs; here the start of an img2img run.
+struct VaeEncoderModel {
+    int in_channels = 3, latent_channels = 4, n_levels = 0, layers_per_block = 0;
+    std::vector<int> boc;
+    int64_t n_params = 0;
+    DevLinear conv_in, conv_out, quant;
+    DevNorm norm_out;
+    struct DownBlock { std::vector<ResnetW> res; DevLinear down; bool has_down = false; };
+    std::vector<DownBlock> down;
+    ResnetW mid_res0, mid_res1;
+    VaeAttnW mid_att;
+
+    void build(const OnnxModel& m, const WeightMap& w, WeightBuilder& b);
+    // x_packed: [B*H*W][64] images in [-1, 1] (3 channels + zero pad); moments: f32 NCHW [B, 2*latent, h, w] (mean | logvar)
+    void forward(Exec& ex, const half_t* x_packed, int B, int H, int W, float* moments) const;
+    int downscale() const { return 1 << (n_levels - 1); }
+    static int out_size(int X, int levels) { for (int i = 0; i + 1 < levels; ++i) X = (X - 2) / 2 + 1; return X; }
+    static constexpr int kInPad = 64;
+};
+
 // uploads + repacks weights; owns every device allocation it makes
 struct WeightBuilder {
     bool gelu_tanh = false;     // the model being built came from the optimizer with --approximate-gelu (FastGelu nodes)

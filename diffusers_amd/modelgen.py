@@ -181,6 +181,38 @@ def vae_decoder_param_shapes(cfg: dict) -> "OrderedDict[str, tuple]":
     return out
 
 
+def vae_encoder_param_shapes(cfg: dict) -> "OrderedDict[str, tuple]":
+    """AutoencoderKL encoder + quant_conv (diffusers 0.14.0 names, as the reference's vae_encoder.onnx fixture carries them)."""
+    out: "OrderedDict[str, tuple]" = OrderedDict()
+    boc = list(cfg["block_out_channels"])
+    lc = cfg["latent_channels"]
+    out["encoder.conv_in.weight"] = (boc[0], cfg["out_channels"], 3, 3)
+    out["encoder.conv_in.bias"] = (boc[0],)
+    c = boc[0]
+    for i, co in enumerate(boc):
+        for j in range(cfg["layers_per_block"]):
+            _resnet_shapes(f"encoder.down_blocks.{i}.resnets.{j}", c, co, 0, out)
+            c = co
+        if i < len(boc) - 1:
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.weight"] = (c, c, 3, 3)
+            out[f"encoder.down_blocks.{i}.downsamplers.0.conv.bias"] = (c,)
+    _resnet_shapes("encoder.mid_block.resnets.0", c, c, 0, out)
+    a = "encoder.mid_block.attentions.0"
+    out[a + ".group_norm.weight"] = (c,)
+    out[a + ".group_norm.bias"] = (c,)
+    for n in ("query", "key", "value", "proj_attn"):
+        out[f"{a}.{n}.weight"] = (c, c)
+        out[f"{a}.{n}.bias"] = (c,)
+    _resnet_shapes("encoder.mid_block.resnets.1", c, c, 0, out)
+    out["encoder.conv_norm_out.weight"] = (c,)
+    out["encoder.conv_norm_out.bias"] = (c,)
+    out["encoder.conv_out.weight"] = (2 * lc, c, 3, 3)
+    out["encoder.conv_out.bias"] = (2 * lc,)
+    out["quant_conv.weight"] = (2 * lc, 2 * lc, 1, 1)
+    out["quant_conv.bias"] = (2 * lc,)
+    return out
+
+
 def random_weights(shapes: Dict[str, tuple], seed: int, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
     """Random-init weights (fan-in scaled so activations stay O(1) through the residual stacks):
     conv/linear ~ N(0, gain/sqrt(fan_in)), norm gamma ~ 1 + 0.1 N, biases/betas ~ 0.05 N."""
@@ -318,11 +350,12 @@ class GraphWriter:
         return out
 
     # --- module emitters (dialect of the fixture) ---
-    def conv(self, scope, pname, w, x, stride=1, k=3):
+    def conv(self, scope, pname, w, x, stride=1, k=3, pad=None):
         out = self.tmp(scope, "Conv")
         self.init(pname + ".weight", w[pname + ".weight"])
         self.init(pname + ".bias", w[pname + ".bias"])
-        pad = 1 if k == 3 else 0
+        if pad is None:
+            pad = 1 if k == 3 else 0
         attrs = (_attr_ints("dilations", [1, 1]) + _attr_i("group", 1) + _attr_ints("kernel_shape", [k, k]) +
                  _attr_ints("pads", [pad] * 4) + _attr_ints("strides", [stride, stride]))
         if self.nv:
@@ -768,6 +801,52 @@ def write_vae_decoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype
     gw.serialize(path, ["latent_sample"], ["sample"], None)
 
 
+def write_vae_encoder_onnx(path: str, cfg: dict, w: Dict[str, np.ndarray], dtype=np.float32):
+    """vae_encoder.onnx in the raw dialect (sd2pyke.py:181-187,325-346): initializer names and node kinds of the reference's
+    fixture export -- Pad (0,1,0,1) + stride-2 pad-0 Conv downsamplers, Slice / Clip / Exp / RandomNormalLike posterior sample.
+    The token reshapes around the mid-block attention are abbreviated as in write_vae_decoder_onnx (the engine and the oracle's
+    restatement bind initializers by name)."""
+    gw = GraphWriter(dtype, False, False, False)
+    groups = cfg["norm_num_groups"]
+    boc = list(cfg["block_out_channels"])
+    lc = cfg["latent_channels"]
+    h = gw.conv("/encoder/conv_in", "encoder.conv_in", w, "sample")
+    for i, co in enumerate(boc):
+        for j in range(cfg["layers_per_block"]):
+            h = _emit_resnet(gw, f"/encoder/down_blocks.{i}/resnets.{j}", f"encoder.down_blocks.{i}.resnets.{j}", w, h, None, 1e-6, groups)
+        if i < len(boc) - 1:
+            s2 = f"/encoder/down_blocks.{i}/downsamplers.0"
+            pd = gw.op("Pad", s2, [h, gw.i64(s2, [0, 0, 0, 0, 0, 0, 1, 1]), gw.const(s2, np.asarray(0.0, np.float32))], _attr_s("mode", "constant"))
+            h = gw.conv(s2 + "/conv", f"encoder.down_blocks.{i}.downsamplers.0.conv", w, pd, stride=2, pad=0)
+    h = _emit_resnet(gw, "/encoder/mid_block/resnets.0", "encoder.mid_block.resnets.0", w, h, None, 1e-6, groups)
+    sc, p = "/encoder/mid_block/attentions.0", "encoder.mid_block.attentions.0"
+    c = boc[-1]
+    n = gw.group_norm(sc + "/group_norm", p + ".group_norm", w, h, 1e-6, groups)
+    q = gw.linear(sc + "/query", p + ".query", w, n)
+    k = gw.linear(sc + "/key", p + ".key", w, n)
+    v = gw.linear(sc + "/value", p + ".value", w, n)
+    s = gw.binary("MatMul", sc, q, k)
+    s = gw.binary("Mul", sc, s, gw.const(sc, np.asarray(c ** -0.5, np.float32)), "Mul_1")
+    s = gw.unary("Softmax", sc, s)
+    o = gw.binary("MatMul", sc, s, v, "MatMul_1")
+    o = gw.linear(sc + "/proj_attn", p + ".proj_attn", w, o)
+    h = gw.binary("Add", sc, o, h)
+    h = _emit_resnet(gw, "/encoder/mid_block/resnets.1", "encoder.mid_block.resnets.1", w, h, None, 1e-6, groups)
+    h = gw.group_norm("/encoder/conv_norm_out", "encoder.conv_norm_out", w, h, 1e-6, groups, swish=True)
+    h = gw.silu("/encoder/conv_act", h)
+    h = gw.conv("/encoder/conv_out", "encoder.conv_out", w, h)
+    m = gw.conv("/quant_conv", "quant_conv", w, h, k=1)
+    ax = gw.i64("/post", [1])
+    mean = gw.op("Slice", "/post", [m, gw.i64("/post", [0]), gw.i64("/post", [lc]), ax], name="Slice")
+    logvar = gw.op("Slice", "/post", [m, gw.i64("/post", [lc]), gw.i64("/post", [2 * lc]), ax], name="Slice_1")
+    logvar = gw.op("Clip", "/post", [logvar, gw.const("/post", np.asarray(-30.0, np.float32)), gw.const("/post", np.asarray(20.0, np.float32))])
+    std = gw.unary("Exp", "/post", gw.binary("Mul", "/post", logvar, gw.const("/post", np.asarray(0.5, np.float32))))
+    nz = gw.op("RandomNormalLike", "/post", [mean], _attr_i("dtype", 1))
+    out = gw.binary("Add", "/post", mean, gw.binary("Mul", "/post", std, nz, "Mul_1"))
+    gw.node("Cast", "/Cast_out", [out], ["latent_sample"], _attr_i("to", 1))
+    gw.serialize(path, ["sample"], ["latent_sample"], None)
+
+
 TOML_TEMPLATE = """v = 2
 pipeline = "stable-diffusion"
 
@@ -805,8 +884,8 @@ vae-decoder = "{vae_hash}"
 
 def write_model_dir(root: str, unet_cfg: dict, vae_cfg: dict, seed: int = 42, dtype=np.float32,
                     unet_gain: float = 1.0, external: bool | None = None, fused: bool = False, approximate_gelu: bool = False,
-                    nv: bool = False):
-    """Writes pyke-diffusers.toml + unet.onnx(+unet_weights.bin) + vae_decoder.onnx with random weights.
+                    nv: bool = False, vae_encoder: bool = False):
+    """Writes pyke-diffusers.toml + unet.onnx(+unet_weights.bin) + vae_decoder.onnx (+ vae_encoder.onnx) with random weights.
     The text-encoder/tokenizer entries are placeholders: CLIP stays with the caller."""
     os.makedirs(root, exist_ok=True)
     uw = random_weights(unet_param_shapes(unet_cfg), seed, unet_gain)
@@ -814,6 +893,11 @@ def write_model_dir(root: str, unet_cfg: dict, vae_cfg: dict, seed: int = 42, dt
     del uw
     vw = random_weights(vae_decoder_param_shapes(vae_cfg), seed + 1)
     write_vae_decoder_onnx(os.path.join(root, "vae_decoder.onnx"), vae_cfg, vw, dtype, fused, nv)
+    toml = TOML_TEMPLATE.format(unet_hash=f"{seed:032x}", vae_hash=f"{seed + 1:032x}")
+    if vae_encoder:
+        ew = random_weights(vae_encoder_param_shapes(vae_cfg), seed + 2)
+        write_vae_encoder_onnx(os.path.join(root, "vae_encoder.onnx"), vae_cfg, ew, dtype)
+        toml = toml.replace('[vae]\ndecoder', '[vae]\nencoder = "vae_encoder.onnx"\ndecoder') + f'vae-encoder = "{seed + 2:032x}"\n'
     with open(os.path.join(root, "pyke-diffusers.toml"), "w") as f:
-        f.write(TOML_TEMPLATE.format(unet_hash=f"{seed:032x}", vae_hash=f"{seed + 1:032x}"))
+        f.write(toml)
     return root

@@ -89,6 +89,28 @@ class StableDiffusionPipeline:
         _lib.check(_lib.lib().sde_vae_decoder_run(self._h, z.ctypes.data, B, h, w, out.ctypes.data))
         return out
 
+    def load_vae_encoder(self, onnx_path: Optional[str] = None):
+        """The `vae_encoder: Option<Session>` of impl_main.rs:58,140-150 (None: the model dir's `[vae] encoder` entry)."""
+        _lib.check(_lib.lib().sde_engine_load_vae_encoder(self._h, onnx_path.encode() if onnx_path else None))
+        return self
+
+    def vae_encoder(self, sample, noise=None) -> np.ndarray:
+        """vae_encoder.run([sample]) of the exported graph (sd2pyke.py:181-187): f32 [B,3,H,W] in [-1,1] -> latent_sample
+        [B,4,H/8,W/8] = mean + std * noise (the graph's RandomNormalLike becomes the `noise` argument; None = posterior mean)."""
+        x = np.ascontiguousarray(sample, np.float32)
+        B, _, H, W = x.shape
+        L = _lib.lib()
+        lc, h, w = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(L.sde_vae_encoder_out_shape(self._h, H, W, C.byref(lc), C.byref(h), C.byref(w)))
+        out = np.empty((B, lc.value, h.value, w.value), np.float32)
+        nz = None
+        if noise is not None:
+            nz = np.ascontiguousarray(noise, np.float32)
+            if nz.shape != out.shape:
+                raise ValueError(f"noise must be {out.shape}, got {nz.shape}")
+        _lib.check(L.sde_vae_encoder_run(self._h, x.ctypes.data, B, H, W, nz.ctypes.data if nz is not None else None, out.ctypes.data))
+        return out
+
     def decode_latents(self, latents) -> np.ndarray:
         """impl_main.rs:398-413 → f32 [B,H,W,3] in [0,1] (the Rgb32F image buffers)."""
         z = np.ascontiguousarray(latents, np.float32)
@@ -159,6 +181,7 @@ class StableDiffusionTxt2ImgOptions:
     callback: Optional[Callable] = None
     init_latents: Optional[np.ndarray] = None
     step_noise: Optional[np.ndarray] = None
+    start_step: int = 0                       # image-to-image: run timesteps[start_step:] from already-noised init_latents
 
     # builder methods (impl_txt2img.rs:67-219)
     def with_size(self, width: int, height: int):
@@ -268,6 +291,7 @@ class StableDiffusionTxt2ImgOptions:
             images = None if skip_decode else np.empty((B, h * up, w * up, 3), np.float32)
             images_ptr = images.ctypes.data if images is not None else None
         o.skip_decode = int(skip_decode)
+        o.start_step = int(self.start_step)
         res = Txt2ImgResult(images=images)
         if self.callback is not None and self.callback_kind != CB_NONE:
             kind = self.callback_kind
@@ -339,6 +363,88 @@ class StableDiffusionTxt2ImgOptions:
         res.unet_calls, res.total_ms, res.unet_ms, res.vae_ms = st.unet_calls, st.total_ms, st.unet_ms, st.vae_ms
         res.host_enqueue_ms = st.host_enqueue_ms
         if trace and res.noise_pred is not None:
-            res.noise_pred = res.noise_pred[:st.unet_calls]
-            res.latents = res.latents[:st.unet_calls]
+            s0 = int(self.start_step)        # rows are indexed by the absolute step: the executed ones are [start_step, start_step + calls)
+            res.noise_pred = res.noise_pred[s0:s0 + st.unet_calls]
+            res.latents = res.latents[s0:s0 + st.unet_calls]
         return res
+
+
+@dataclass
+class StableDiffusionImg2ImgOptions:
+    """Mirror of impl_img2img.rs:18-34 (fields, defaults, builder names).  The reference stops there: it has no `run` for these
+    options, so `run` below follows diffusers 0.14.0's StableDiffusionImg2ImgPipeline, the pipeline pyke Diffusers tracks:
+    image -> 2x - 1 -> VAE encoder posterior sample -> * 0.18215 -> scheduler.add_noise at timesteps[t_start] -> the txt2img loop
+    over timesteps[t_start:], t_start = steps - min(int(steps * noise_strength), steps).  Randomness (no reference stream exists for
+    it): the posterior noise, then the added noise, are consecutive draws of sde_rng_standard_normal(seed)."""
+    reference_image: Optional[np.ndarray] = None      # f32 [B,3,H,W] in [0,1] (what with_image builds, :177-191)
+    noise_strength: float = 0.6
+    text_config: StableDiffusionTxt2ImgOptions = field(default_factory=StableDiffusionTxt2ImgOptions)
+
+    def with_size(self, width: int, height: int):
+        self.text_config.with_size(width, height)
+        self.reference_image = None                    # :69-71 drop_reference_image
+        return self
+
+    def with_steps(self, steps: int):
+        self.text_config.steps = steps
+        return self
+
+    def with_noise_strength(self, s: float):
+        self.noise_strength = min(max(float(s), 0.0), 1.0)     # :141-144
+        return self
+
+    def with_seed(self, seed: int):
+        self.text_config.seed = seed
+        return self
+
+    def with_guidance_scale(self, g: float):
+        self.text_config.guidance_scale = g
+        return self
+
+    def with_text_embeddings(self, ehs, batch_size: int):
+        self.text_config.with_text_embeddings(ehs, batch_size)
+        return self
+
+    def with_images(self, images_nhwc01):
+        """:194-208 -- [B,H,W,3] in [0,1], already at the configured size (resizing stays with the caller's image library)."""
+        x = np.ascontiguousarray(images_nhwc01, np.float32)
+        if x.ndim != 4 or x.shape[3] != 3:
+            raise ValueError(f"images must be [B,H,W,3], got {x.shape}")
+        self.reference_image = np.ascontiguousarray(x.transpose(0, 3, 1, 2))
+        return self
+
+    def start_step(self) -> int:
+        steps = self.text_config.steps
+        return max(steps - min(int(steps * self.noise_strength), steps), 0)
+
+    def run(self, session: StableDiffusionPipeline, scheduler: DiffusionScheduler, **kw) -> Txt2ImgResult:
+        from . import _lib as L_
+        tc = self.text_config
+        if self.reference_image is None:
+            raise ValueError("reference_image is not set")
+        img = np.ascontiguousarray(self.reference_image, np.float32)
+        B = img.shape[0]
+        if B != tc.batch_size:
+            raise ValueError("one reference image per prompt")
+        seed = tc.seed if tc.seed is not None else int(np.random.SeedSequence().generate_state(1, np.uint64)[0])
+        scheduler.set_timesteps(tc.steps)
+        ts = scheduler.timesteps()
+        t0 = self.start_step()
+        lat_shape = (B, 4, tc.height // 8, tc.width // 8)
+        n = int(np.prod(lat_shape))
+        draws = np.empty(2 * n, np.float32)
+        L_.check(L_.lib().sde_rng_standard_normal(C.c_uint64(seed), C.c_uint64(0), draws.ctypes.data, draws.size))
+        lc, hh, ww = C.c_int(), C.c_int(), C.c_int()
+        L_.check(L_.lib().sde_vae_encoder_out_shape(session._h, img.shape[2], img.shape[3], C.byref(lc), C.byref(hh), C.byref(ww)))
+        if (lc.value, hh.value, ww.value) != lat_shape[1:]:
+            raise ValueError(f"a {img.shape[2]}x{img.shape[3]} image encodes to {hh.value}x{ww.value} latents, the run is configured for "
+                             f"{lat_shape[2]}x{lat_shape[3]} (height/8 x width/8)")
+        z = session.vae_encoder(2.0 * img - 1.0, draws[:n].reshape(lat_shape))
+        z = (np.float32(0.18215) * z).astype(np.float32)
+        if t0 >= len(ts):                                   # strength 0: nothing to denoise
+            return Txt2ImgResult(images=session.decode_latents(z), unet_calls=0)
+        noised = scheduler.add_noise(z, draws[n:].reshape(lat_shape), float(ts[t0]))
+        import copy
+        cfg = copy.copy(tc)
+        cfg.seed, cfg.init_latents, cfg.start_step = seed, noised, t0
+        return cfg.run(session, scheduler, **kw)

@@ -105,6 +105,17 @@ sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, in
 #define SDE_NOALLOC_SCRATCH_BYTES (8u << 20)
 sde_status sde_approximate_decode_noalloc(sde_engine* e, const float* latents, int B, int h, int w, float* images_nhwc);
 
+/* VAE encoder: the reference opens this session when the model dir names one (`vae_encoder: Option<Session>`, impl_main.rs:58,140-150;
+ * `replace_vae`, :315-320) and never runs it -- impl_img2img.rs only builds options.  Loading is therefore a call of its own.
+ * onnx_path NULL: the `[vae] encoder` entry of the model dir the engine was created from (config.rs:91). */
+sde_status sde_engine_load_vae_encoder(sde_engine* e, const char* onnx_path);
+/* The bare session call of the exported graph (sd2pyke.py:181-187,325-346): `sample` f32 [B,3,H,W] in [-1,1] -> `latent_sample`
+ * f32 [B,4,H/8,W/8] = mean + exp(0.5 clamp(logvar, -30, 20)) * noise.  The graph draws its noise with RandomNormalLike; here the
+ * caller passes it (f32 [B,4,H/8,W/8], e.g. from sde_rng_standard_normal), or NULL for the posterior mean.  Not scaled by 0.18215. */
+sde_status sde_vae_encoder_run(sde_engine* e, const float* sample_nchw, int B, int H, int W, const float* noise, float* latent_sample);
+/* shape of latent_sample for an H x W image: every level but the last halves the size as a pad-(0,1,0,1), stride-2, 3x3 window does */
+sde_status sde_vae_encoder_out_shape(const sde_engine* e, int H, int W, int* latent_channels, int* h, int* w);
+
 /* Schedulers (trait DiffusionScheduler, schedulers/mod.rs:154-192) -------------------------- */
 typedef enum sde_scheduler_kind {
     SDE_SCHED_EULER = 0,   /* euler_discrete.rs */
@@ -211,6 +222,11 @@ typedef struct sde_txt2img_opts {
      * 0 = not stated (then `steps` rows are assumed and a scheduler that yields more timesteps is rejected). */
     int trace_rows;             /* rows of noise_pred_out / latents_out */
     int step_noise_rows;        /* rows of step_noise */
+    /* image-to-image start (no `run` for it exists in the reference, impl_img2img.rs; the arithmetic is diffusers 0.14.0's
+     * StableDiffusionImg2ImgPipeline): the loop runs timesteps[start_step ..] only and `init_latents` (required when start_step > 0)
+     * are taken as they are -- already noised by sde_scheduler_add_noise(0.18215 * encoded image, noise, timesteps[start_step]) --
+     * instead of being multiplied by init_noise_sigma.  Callback / trace indices stay absolute (first call has step = start_step). */
+    int start_step;
 } sde_txt2img_opts;
 
 void sde_txt2img_opts_default(sde_txt2img_opts* o);

@@ -28,17 +28,27 @@ def cfg_combine(noise_pred: np.ndarray, guidance: float, rescale_cfg: Optional[f
 
 
 def run(unet: Callable[[np.ndarray, float, np.ndarray], np.ndarray], scheduler, ehs: np.ndarray, init_noise: np.ndarray,
-        steps: int, guidance: float = 7.5, rescale_cfg: Optional[float] = None, step_noise: Optional[np.ndarray] = None):
+        steps: int, guidance: float = 7.5, rescale_cfg: Optional[float] = None, step_noise: Optional[np.ndarray] = None,
+        start_step: int = 0):
     """Returns dict(timesteps, noise_pred [n,B,4,h,w], latents [n,B,4,h,w], final [B,4,h,w]).
 
     ``unet(x, t, ehs)`` plays session.unet.run; ``init_noise`` are the N(0,1) draws of :261-262;
-    ``step_noise[i]`` the scheduler's draw at step i (Euler-a / DDPM)."""
+    ``step_noise[i]`` the scheduler's draw at step i (Euler-a / DDPM).
+
+    ``start_step`` > 0 is the image-to-image variant, which the reference does not have (impl_img2img.rs builds options only); it
+    follows diffusers 0.14.0's StableDiffusionImg2ImgPipeline: ``init_noise`` are then the already-noised latents
+    (scheduler.add_noise(0.18215 * encode(image), noise, timesteps[start_step])), taken as they are, and the loop runs
+    timesteps[start_step:]; step_noise stays indexed by the absolute step."""
     do_cfg = guidance > 1.0                                   # :258
     scheduler.set_timesteps(steps)                            # :264
     latents = (init_noise.astype(np.float32) * f32(scheduler.init_noise_sigma())).astype(np.float32)  # :265
+    if start_step > 0:
+        latents = init_noise.astype(np.float32).copy()
     ts = np.array(scheduler.timesteps).copy()
     preds, lats = [], []
     for i, t in enumerate(ts):
+        if i < start_step:
+            continue
         x = np.concatenate([latents, latents], 0) if do_cfg else latents.copy()   # :273-277
         x = scheduler.scale_model_input(x, t)                                      # :278
         np_ = unet(x, float(t), ehs).astype(np.float32)                            # :283
@@ -47,4 +57,4 @@ def run(unet: Callable[[np.ndarray, float, np.ndarray], np.ndarray], scheduler, 
         latents = scheduler.step(eps, t, latents, nz)                              # :303-304
         preds.append(eps)
         lats.append(latents.copy())
-    return dict(timesteps=ts, noise_pred=np.stack(preds), latents=np.stack(lats), final=latents)
+    return dict(timesteps=ts[start_step:], noise_pred=np.stack(preds), latents=np.stack(lats), final=latents)

@@ -57,7 +57,9 @@ pub struct sde_txt2img_opts { pub height: c_int, pub width: c_int, pub guidance_
     pub callback: sde_callback_fn, pub callback_user: *mut c_void,
     pub noise_pred_out: *mut c_float, pub latents_out: *mut c_float, pub final_latents_out: *mut c_float,
     pub cfg_half: c_int, pub exchange: sde_exchange_fn, pub exchange_user: *mut c_void,
-    pub trace_rows: c_int, pub step_noise_rows: c_int }
+    pub trace_rows: c_int, pub step_noise_rows: c_int,
+    /// image-to-image: run timesteps[start_step..] from already-noised `init_latents` (no counterpart in the reference's run)
+    pub start_step: c_int }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct sde_run_stats { pub unet_calls: c_int, pub total_ms: c_float, pub unet_ms: c_float, pub vae_ms: c_float, pub host_enqueue_ms: c_float }
@@ -81,6 +83,11 @@ extern "C" {
     pub fn sde_vae_decode(e: *mut sde_engine, latents: *const c_float, b: c_int, h: c_int, w: c_int, images: *mut c_float) -> c_int;
     pub fn sde_vae_decode_dev(e: *mut sde_engine, d_latents: *const c_float, b: c_int, h: c_int, w: c_int, d_images: *mut c_float) -> c_int;
     pub fn sde_vae_decoder_run(e: *mut sde_engine, z: *const c_float, b: c_int, h: c_int, w: c_int, sample: *mut c_float) -> c_int;
+    /// `vae_encoder: Option<Session>` (impl_main.rs:58,140-150); NULL path = the model dir's `[vae] encoder`
+    pub fn sde_engine_load_vae_encoder(e: *mut sde_engine, onnx_path: *const c_char) -> c_int;
+    /// `vae_encoder.run([sample]) -> latent_sample`; the graph's RandomNormalLike is the `noise` argument (NULL = posterior mean)
+    pub fn sde_vae_encoder_run(e: *mut sde_engine, sample: *const c_float, b: c_int, h: c_int, w: c_int, noise: *const c_float, latent_sample: *mut c_float) -> c_int;
+    pub fn sde_vae_encoder_out_shape(e: *const sde_engine, h_img: c_int, w_img: c_int, latent_channels: *mut c_int, h: *mut c_int, w: *mut c_int) -> c_int;
     pub fn sde_approximate_decode(e: *mut sde_engine, latents: *const c_float, b: c_int, h: c_int, w: c_int, images: *mut c_float) -> c_int;
     pub fn sde_approximate_decode_noalloc(e: *mut sde_engine, latents: *const c_float, b: c_int, h: c_int, w: c_int, images: *mut c_float) -> c_int;
     pub fn sde_sched_cfg_sd_v1(kind: c_int, cfg: *mut sde_sched_cfg);

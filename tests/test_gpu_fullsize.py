@@ -265,3 +265,29 @@ def test_config4_sd21_ddim_v_batch4_loop():
                               sched_kw=dict(prediction_type="v_prediction"), oracle_kw=dict(prediction_type="v_prediction"), pick=[3])
     finally:
         pipe.close()
+
+
+def test_sd_vae_encoder_fullsize(sd15):
+    """The SD VAE encoder geometry (128/256/512/512, 2 resnets per level, 512-wide single-head attention at 1/8 size) on 256x256
+    and 200x264 images, batch 2: the 256x256-tile conv kernel with the asymmetric-pad stride-2 window, the wide-attention GEMM path.
+    Random weights written by modelgen (fp16 initializers), oracle = the torch restatement that is pinned on the reference's own
+    vae_encoder.onnx fixture (tests/test_oracle_fixture_graphs.py)."""
+    from diffusers_amd import modelgen
+    from oracle import fixture_models as FM, onnx_io
+    pipe = sd15[0]
+    path = os.path.join(MODEL_DIR, "vae_encoder_test.onnx")
+    if not os.path.exists(path):
+        cfg = modelgen.vae_config()
+        modelgen.write_vae_encoder_onnx(path, cfg, modelgen.random_weights(modelgen.vae_encoder_param_shapes(cfg), 44), np.float16)
+    pipe.load_vae_encoder(path)
+    w = FM.bind_all(onnx_io.load(path))
+    rng = np.random.default_rng(8)
+    for (B, H, W) in ((2, 256, 256), (1, 200, 264)):
+        x = rng.uniform(-1, 1, (B, 3, H, W)).astype(np.float32)
+        with torch.no_grad():
+            mean = FM.vae_encoder(w, torch.from_numpy(x), None).numpy()
+            nz = rng.standard_normal(mean.shape).astype(np.float32)
+            ref = FM.vae_encoder(w, torch.from_numpy(x), torch.from_numpy(nz)).numpy()
+        assert mean.shape == (B, 4, H // 8, W // 8)
+        assert rel_l2(pipe.vae_encoder(x), mean) < 1e-2
+        assert rel_l2(pipe.vae_encoder(x, nz), ref) < 1e-2
