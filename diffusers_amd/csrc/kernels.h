@@ -130,6 +130,10 @@ void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows
 // y = LayerNorm(S32 + A + B) with the sum formed and kept in fp32 (any of the three may be null, not all); S32_out (optional) receives the sum
 void launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows, int C,
                           const float* gamma, const float* beta, float eps);
+// fp16 engine: y = LayerNorm((A + B) + C) with the sum in fp32 registers only (C may be null); Y4 = half(((A + B) + C) + D) likewise
+void launch_layernorm_sum3(const LaunchCtx& ctx, const half_t* A, const half_t* B, const half_t* Cc, half_t* Y, int rows, int C, const float* gamma,
+                           const float* beta, float eps);
+void launch_sum_round4(const LaunchCtx& ctx, const half_t* A, const half_t* B, const half_t* Cc, const half_t* Dd, half_t* Y, half_t* Ylo, int64_t n);
 // Y = half(S32 + A + B), n elements (n % 8 == 0); Ylo (optional) receives the low part half(sum - Y) of a split-fp16 result
 void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, half_t* Ylo, int64_t n);
 // in-place softmax over the last dim of a [rows][cols] fp16 matrix (fp32 math)

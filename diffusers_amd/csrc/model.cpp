@@ -288,27 +288,40 @@ Tn transformer(Exec& ex, const TransformerW& t, Tn x, int NB, int H, int W, cons
     half_t* y1 = ex.arena->act((size_t)M * C);
     linear(ex, t.out1, ao, C, M, y1, C);
     // cross-attention (K/V of the text tokens come from the per-run cache)
-    float* s1 = ex.arena->get<float>((size_t)M * C);          // s1 = y0 + y1 (fp32)
-    if (!ex.dry()) launch_layernorm_sum(ex.ctx, nullptr, y0, y1, s1, n, M, C, t.ln2.gamma, t.ln2.beta, 1e-5f);
+    // fp16 engine: the fp32 sums exist in registers only -- each consumer re-adds the fp16 branch outputs in the same order
+    // ((y0 + y1) + y2) + y3, so no fp32 tensor is written or re-read (4 B per element less than carrying the sum in memory).
+    // fp32 engine: the running sum s1 is an ordinary tensor.
+    const bool f32 = ex.ctx.f32;
+    float* s1 = f32 ? ex.arena->get<float>((size_t)M * C) : nullptr;          // s1 = y0 + y1
+    if (!ex.dry()) {
+        if (f32) launch_layernorm_sum(ex.ctx, nullptr, y0, y1, s1, n, M, C, t.ln2.gamma, t.ln2.beta, 1e-5f);
+        else launch_layernorm_sum3(ex.ctx, y0, y1, nullptr, n, M, C, t.ln2.gamma, t.ln2.beta, 1e-5f);
+    }
     half_t* q = qkv;  // reuse
     linear(ex, t.q2, n, C, M, q, C);
     attention(ex, q, C, kv, 2 * C, at(ex, kv, C), 2 * C, ao, C, NB, t.heads, HW, S, d);
-    half_t* y2 = y0;  // y0 is folded into s1
+    half_t* y2 = f32 ? y0 : ex.arena->act((size_t)M * C);   // fp32 engine: y0 is folded into s1
     linear(ex, t.out2, ao, C, M, y2, C);
     // GEGLU feed-forward
-    if (!ex.dry()) launch_layernorm_sum(ex.ctx, s1, y2, nullptr, nullptr, n, M, C, t.ln3.gamma, t.ln3.beta, 1e-5f);
+    if (!ex.dry()) {
+        if (f32) launch_layernorm_sum(ex.ctx, s1, y2, nullptr, nullptr, n, M, C, t.ln3.gamma, t.ln3.beta, 1e-5f);
+        else launch_layernorm_sum3(ex.ctx, y0, y1, y2, n, M, C, t.ln3.gamma, t.ln3.beta, 1e-5f);
+    }
     half_t* g = ex.arena->act((size_t)M * 4 * C);
-    if (ex.ctx.f32) {   // fp32 engine: plain projection, then the GEGLU product as its own kernel
+    if (f32) {   // fp32 engine: plain projection, then the GEGLU product as its own kernel
         half_t* y8 = ex.arena->act((size_t)M * 8 * C);
         linear(ex, t.ff1, n, C, M, y8, 8 * C);
         if (!ex.dry()) f32_launch_geglu(ex.ctx, y8, g, M, 4 * C, t.ff1.gelu_tanh ? 1 : 0);
     } else
         linear(ex, t.ff1, n, C, M, g, 4 * C);
-    half_t* y3 = y1;  // y1 is folded into s1
+    half_t* y3 = f32 ? y1 : ao;   // the attention output buffer is dead by now (fp32 engine: y1 is folded into s1)
     linear(ex, t.ff2, g, 4 * C, M, y3, C);
-    half_t* h1 = n;   // the normalised copy is dead: h1 = half(s1 + y2 + y3)
+    half_t* h1 = n;   // the normalised copy is dead: h1 = half(((y0 + y1) + y2) + y3)
     half_t* h1lo = (out.lo && t.proj_out2.W) ? ex.arena->act((size_t)M * C) : nullptr;   // proj_out reads [h1 | h1lo] against [W | W]
-    if (!ex.dry()) launch_sum_round(ex.ctx, s1, y2, y3, h1, h1lo, (int64_t)M * C);
+    if (!ex.dry()) {
+        if (f32) launch_sum_round(ex.ctx, s1, y2, y3, h1, h1lo, (int64_t)M * C);
+        else launch_sum_round4(ex.ctx, y0, y1, y2, y3, h1, h1lo, (int64_t)M * C);
+    }
     if (h1lo) linear(ex, t.proj_out2, h1, C, M, out.hi, C, x.hi, C, h1lo, C, C, C, x.lo, out.lo);
     else linear(ex, t.proj_out, h1, C, M, out.hi, C, x.hi, C, nullptr, 0, 0, 0, x.lo, out.lo);
     ex.arena->release(mk);

@@ -412,8 +412,8 @@ void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows
 // stay fp16 GEMM outputs, the running sum is never rounded to fp16 between sub-layers (the rounding of the
 // residual stream at every residual add was the largest single contribution to the engine-vs-fp32 error).
 template <int NOCT, int LN_ROWS>
-__global__ __launch_bounds__(256) void layernorm_sum_kernel(const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows,
-                                                            int C, const float* gamma, const float* beta, float eps)
+__global__ __launch_bounds__(256) void layernorm_sum_kernel(const float* S32, const half_t* A, const half_t* B, const half_t* Cc, float* S32_out, half_t* Y,
+                                                            int rows, int C, const float* gamma, const float* beta, float eps)
 {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LN_ROWS;
@@ -440,6 +440,11 @@ __global__ __launch_bounds__(256) void layernorm_sum_kernel(const float* S32, co
                     half8 b = *(const half8*)(B + off + cx * 8);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[r][o][j] += (float)b[j];
+                }
+                if (Cc) {
+                    half8 c = *(const half8*)(Cc + off + cx * 8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[r][o][j] += (float)c[j];
                 }
             }
         }
@@ -485,16 +490,29 @@ __global__ __launch_bounds__(256) void layernorm_sum_kernel(const float* S32, co
     }
 }
 
+static void launch_layernorm_sum_impl(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, const half_t* Cc, float* S32_out, half_t* Y,
+                                      int rows, int C, const float* gamma, const float* beta, float eps);
 void launch_layernorm_sum(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, float* S32_out, half_t* Y, int rows, int C,
                           const float* gamma, const float* beta, float eps)
 {
     SDE_REQUIRE(S32 || A || B, SDE_ERR_INVALID_ARGUMENT, "layernorm_sum: no input");
     if (ctx.f32) { f32_launch_layernorm_sum(ctx, S32, A, B, S32_out, Y, rows, C, gamma, beta, eps); return; }
+    launch_layernorm_sum_impl(ctx, S32, A, B, nullptr, S32_out, Y, rows, C, gamma, beta, eps);
+}
+void launch_layernorm_sum3(const LaunchCtx& ctx, const half_t* A, const half_t* B, const half_t* Cc, half_t* Y, int rows, int C, const float* gamma,
+                           const float* beta, float eps)
+{
+    SDE_REQUIRE(!ctx.f32 && A && B, SDE_ERR_INVALID_ARGUMENT, "layernorm_sum3: fp16 engine, at least two terms");
+    launch_layernorm_sum_impl(ctx, nullptr, A, B, Cc, nullptr, Y, rows, C, gamma, beta, eps);
+}
+static void launch_layernorm_sum_impl(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, const half_t* Cc, float* S32_out, half_t* Y,
+                                      int rows, int C, const float* gamma, const float* beta, float eps)
+{
     SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
-    ProfScope ps(ctx, "layernorm_sum", 0, (double)rows * C * ((S32 ? 4.0 : 0.0) + (A ? 2.0 : 0.0) + (B ? 2.0 : 0.0) + (S32_out ? 4.0 : 0.0) + 2.0));
+    ProfScope ps(ctx, "layernorm_sum", 0, (double)rows * C * ((S32 ? 4.0 : 0.0) + (A ? 2.0 : 0.0) + (B ? 2.0 : 0.0) + (Cc ? 2.0 : 0.0) + (S32_out ? 4.0 : 0.0) + 2.0));
     const int noct = cdiv(C / 8, 64);
     const dim3 block(256);
-#define LN_LAUNCH(O, R) hipLaunchKernelGGL((layernorm_sum_kernel<O, R>), dim3(cdiv(rows, 4 * R)), block, 0, ctx.stream, S32, A, B, S32_out, Y, rows, C, gamma, beta, eps)
+#define LN_LAUNCH(O, R) hipLaunchKernelGGL((layernorm_sum_kernel<O, R>), dim3(cdiv(rows, 4 * R)), block, 0, ctx.stream, S32, A, B, Cc, S32_out, Y, rows, C, gamma, beta, eps)
     if (rows >= 32768 && noct <= 2) {
         if (noct == 1) LN_LAUNCH(1, 4); else LN_LAUNCH(2, 4);
     } else if (rows >= 8192) {
@@ -523,6 +541,30 @@ __global__ void sum_round_kernel(const float* S32, const half_t* A, const half_t
         *(half8*)(Y + i * 8) = o;
         if (Ylo) *(half8*)(Ylo + i * 8) = l;
     }
+}
+// y = half(((A + B) + C) + D) in fp32: the same block-final sum from the four fp16 branch outputs themselves (no fp32 tensor in between)
+__global__ void sum_round4_kernel(const half_t* A, const half_t* B, const half_t* Cc, const half_t* Dd, half_t* Y, half_t* Ylo, long long n8)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const half8 a = *(const half8*)(A + i * 8), b = *(const half8*)(B + i * 8), c = *(const half8*)(Cc + i * 8), d = *(const half8*)(Dd + i * 8);
+        half8 o, l;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (((float)a[j] + (float)b[j]) + (float)c[j]) + (float)d[j];
+            o[j] = (half_t)x;
+            l[j] = (half_t)(x - (float)o[j]);
+        }
+        *(half8*)(Y + i * 8) = o;
+        if (Ylo) *(half8*)(Ylo + i * 8) = l;
+    }
+}
+void launch_sum_round4(const LaunchCtx& ctx, const half_t* A, const half_t* B, const half_t* Cc, const half_t* Dd, half_t* Y, half_t* Ylo, int64_t n)
+{
+    SDE_REQUIRE(!ctx.f32 && n % 8 == 0 && A && B && Cc && Dd, SDE_ERR_INVALID_ARGUMENT, "sum_round4: bad arguments");
+    ProfScope ps(ctx, "residual_sum_round", 0, (Ylo ? 12.0 : 10.0) * n);
+    hipLaunchKernelGGL(sum_round4_kernel, dim3((unsigned)std::min<long long>(cdiv64(n / 8, 256), 8192)), dim3(256), 0, ctx.stream, A, B, Cc, Dd, Y, Ylo,
+                       (long long)(n / 8));
+    HIP_CHECK(hipGetLastError());
 }
 void launch_sum_round(const LaunchCtx& ctx, const float* S32, const half_t* A, const half_t* B, half_t* Y, half_t* Ylo, int64_t n)
 {
