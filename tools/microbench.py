@@ -12,7 +12,7 @@ CONVS = [  # H, Cin, Cout, k, stride, ups
     (64, 320, 320, 3, 1, 0), (64, 640, 320, 3, 1, 0), (32, 640, 640, 3, 1, 0), (32, 1280, 640, 3, 1, 0), (16, 1280, 1280, 3, 1, 0),
     (16, 2560, 1280, 3, 1, 0), (8, 1280, 1280, 3, 1, 0), (8, 2560, 1280, 3, 1, 0), (32, 320, 320, 3, 1, 1), (64, 320, 320, 3, 2, 0),
     (64, 320, 320, 1, 1, 0), (64, 320, 960, 1, 1, 0), (64, 1280, 320, 1, 1, 0), (32, 640, 640, 1, 1, 0), (32, 2560, 640, 1, 1, 0),
-    (16, 1280, 1280, 1, 1, 0), (16, 5120, 1280, 1, 1, 0), (64, 320, 2560, 1, 1, 0),
+    (16, 1280, 1280, 1, 1, 0), (16, 2560, 1280, 1, 1, 0), (16, 5120, 1280, 1, 1, 0), (64, 320, 2560, 1, 1, 0),
     (64, 64, 320, 1, 1, 0), (64, 64, 2560, 1, 1, 0),   # one K-tile: prologue + epilogue cost of the 256x320 kernel (1 and 8 rounds of blocks)
 ]
 ATTN = [(8, 4096, 4096, 40), (8, 1024, 1024, 80), (8, 256, 256, 160), (8, 4096, 77, 40), (8, 1024, 77, 80)]
@@ -30,7 +30,7 @@ def main():
     reps = 4
     only = os.environ.get("MB_ONLY", "")
     convs = [c for c in CONVS if not only or (only == "small" and NB * c[0] * c[0] <= 4096) or (only == "big" and NB * c[0] * c[0] > 4096)
-             or (only == "c64" and c[0] == 64 and c[3] == 3 and c[4] == 1) or (only == "k64" and c[1] == 64) or (only == "wide" and c[3] == 1 and c[2] >= 960) or (only == "lin64" and c[0] == 64 and c[3] == 1 and c[1] >= 320) or (only == "c32" and c[0] == 32 and c[3] == 3 and c[5] == 0)]
+             or (only == "c64" and c[0] == 64 and c[3] == 3 and c[4] == 1) or (only == "k64" and c[1] == 64) or (only == "wide" and c[3] == 1 and c[2] >= 960) or (only == "lin16" and c[0] == 16 and c[3] == 1) or (only == "lin64" and c[0] == 64 and c[3] == 1 and c[1] >= 320) or (only == "c32" and c[0] == 32 and c[3] == 3 and c[5] == 0)]
     for (H, Cin, Cout, k, stride, ups) in convs:
         x = rng.standard_normal((NB, H, H, Cin), dtype=np.float32)
         w = (rng.standard_normal((Cout, Cin, k, k), dtype=np.float32) / np.sqrt(Cin * k * k)).astype(np.float32)
