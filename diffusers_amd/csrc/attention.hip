@@ -203,27 +203,38 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             }
     }
 
-    auto tile = [&](int kv0, int buf, auto mask_tag) {
+    // State of the tile in flight.  It lives outside the lambda because the LDS-DMA loop runs a tile in two steps when a running
+    // maximum has to be raised (mode 1 = scores + the common-path finish, mode 2 = the rescaling finish, see that loop).
+    floatx4 s[4][2];
+    fp16x4 vlo[2][DVT], vhi[2][DVT];
+    float mxq[2];
+    bool trigq[2];
+    // mode 0: the whole tile.  mode 1: scores; if no query of the wave raises its maximum, finish the tile and return false, else
+    // return true with the tile unfinished.  mode 2: finish such a tile (rescale, then exp / PV).
+    auto issue_v_reads = [&](const half_t* sV) {
+        const int tq = fr >> 2, tp = fr & 3;
+        const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sV + (fg * 4 + tq) * VROW + tp * 4);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < DVT; ++dt) {
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + dt * 16) * 2));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + 16 * VROW + dt * 16) * 2));
+            }
+    };
+    auto tile = [&](int kv0, int buf, auto mask_tag, auto mode_tag) -> bool {
         constexpr bool MASK = decltype(mask_tag)::value;
+        constexpr int MODE = decltype(mode_tag)::value;
         const half_t* sK = sK_ + buf * 64 * KROW;
         const half_t* sV = sV_ + buf * 64 * VROW;
         const int tq = fr >> 2, tp = fr & 3;
+        bool any_trig = false;
+        if constexpr (MODE != 2) {
         // DMA path: the transposed V reads go out FIRST, ahead of the K-fragment reads.  LDS returns in order, so the waits the
         // compiler places for its own K reads (it does not know about the asm reads in front of them) also cover V, and the V
         // latency hides behind the score MFMAs instead of sitting between the running-max phase and the exponentials.
-        fp16x4 vlo[2][DVT], vhi[2][DVT];
-        if constexpr (DMA) {
-            const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(sV + (fg * 4 + tq) * VROW + tp * 4);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int dt = 0; dt < DVT; ++dt) {
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vlo[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + dt * 16) * 2));
-                    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vhi[s2][dt]) : "v"(va), "n"((s2 * 32 * VROW + 16 * VROW + dt * 16) * 2));
-                }
-        }
+        if constexpr (DMA) issue_v_reads(sV);
         // scores S^T[key][q]: s[kt][qt][r] <-> key = kv0 + 16*kt + 4*fg + r, q = q0 + 16*qt + fr
-        floatx4 s[4][2];
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) { s[kt][0] = floatx4{0, 0, 0, 0}; s[kt][1] = floatx4{0, 0, 0, 0}; }
 #pragma unroll
@@ -235,7 +246,12 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
                 s[kt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[1][ks], s[kt][1], 0, 0, 0);
             }
         }
-        // phase 1 (per q-tile): mask, running max, deferred rescale (branchy, short)
+        // phase 1: mask, lane-local maxima, then ONE block-uniform branch: the common path (no query of this wave raises its
+        // running max) goes straight to phase 2; the rare path rescales and then runs its own copy of phase 2.  With the branch
+        // rejoining before phase 2 the compiler kept O and the Q fragments in two register sets and copied them across twice
+        // per tile (40 v_mov_b64); with the two paths meeting only at the loop's back edge each keeps them where they are.
+        bool trig = false;
+        trigq[0] = trigq[1] = false;
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
             if (MASK) {
@@ -252,51 +268,54 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][qt][r]);
+            mxq[qt] = mx;
             // deferred rescale: raise the running max only when it grows by more than THR (log2 units)
+            if (FOLD) trigq[qt] = mx > ATTN_RESCALE_THR || mrow[qt] == -INFINITY;   // scores are already s*c - M_old: mx is the growth
+            else trigq[qt] = mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY;
+            trig = trig || trigq[qt];
+        }
+        if constexpr (DMA) any_trig = __any(trig);
+        }   // MODE != 2
+        auto rescale = [&](int qt) {
+            float mx = mxq[qt];
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
             if (FOLD) {
-                // scores are already s*c - M_old (M_old = 0 before the first tile): mx is the growth of the maximum
                 const bool first = mrow[qt] == -INFINITY;
-                if (__any(mx > ATTN_RESCALE_THR || first)) {
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
-                    const bool grow = mx > ATTN_RESCALE_THR || first;
-                    const float delta = grow ? mx : 0.f;
-                    const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
-                    mrow[qt] = (first ? 0.f : mrow[qt]) + delta;
-                    lrow[qt] *= alpha;
+                const bool grow = mx > ATTN_RESCALE_THR || first;
+                const float delta = grow ? mx : 0.f;
+                const float alpha = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                mrow[qt] = (first ? 0.f : mrow[qt]) + delta;
+                lrow[qt] *= alpha;
+            #pragma unroll
+                for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
-                    for (int dt = 0; dt < DVT; ++dt)
+                    for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                    for (int kt = 0; kt < 4; ++kt)
+                    for (int r = 0; r < 4; ++r) s[kt][qt][r] -= delta;
+                const half_t hi = (half_t)(-mrow[qt]);
+                const half_t lo = (half_t)(-mrow[qt] - (float)hi);
+                if (fg == fg_e) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) s[kt][qt][r] -= delta;
-                    const half_t hi = (half_t)(-mrow[qt]);
-                    const half_t lo = (half_t)(-mrow[qt] - (float)hi);
-                    if (fg == fg_e) {
-#pragma unroll
-                        for (int ks = 0; ks < KS; ++ks)
-                            if (ks == ks_e) { qf[qt][ks][0] = hi; qf[qt][ks][1] = lo; }
-                    }
+                    for (int ks = 0; ks < KS; ++ks)
+                        if (ks == ks_e) { qf[qt][ks][0] = hi; qf[qt][ks][1] = lo; }
                 }
             } else {
-                if (__any(mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY)) {
-                    mx = fmaxf(mx, __shfl_xor(mx, 16));
-                    mx = fmaxf(mx, __shfl_xor(mx, 32));
-                    const bool grow = mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY;
-                    float mnew = grow ? mx : mrow[qt];
-                    float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * csl);   // exp2(-inf) = 0 on the first tile
-                    if (mrow[qt] == mnew) alpha = 1.0f;
-                    mrow[qt] = mnew;
-                    lrow[qt] *= alpha;
+                const bool grow = mx * csl > mrow[qt] * csl + ATTN_RESCALE_THR || mrow[qt] == -INFINITY;
+                float mnew = grow ? mx : mrow[qt];
+                float alpha = __builtin_amdgcn_exp2f((mrow[qt] - mnew) * csl);   // exp2(-inf) = 0 on the first tile
+                if (mrow[qt] == mnew) alpha = 1.0f;
+                mrow[qt] = mnew;
+                lrow[qt] *= alpha;
+            #pragma unroll
+                for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
-                    for (int dt = 0; dt < DVT; ++dt)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
-                }
+                    for (int r = 0; r < 4; ++r) o[dt][qt][r] *= alpha;
             }
-        }
+        };
+        auto phase2 = [&]() {
         // phase 2 (straight line): V^T fragments, then exp / PV per q-tile so that the second tile's exponentials can
         // be scheduled between the first tile's PV MFMAs.
         // A operand via transposed LDS reads: lane 4q'+p' of a 16-lane group addresses row (key) q', columns 4p'..4p'+3
@@ -355,7 +374,36 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
                     o[dt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(v, pf[s2], o[dt][qt], 0, 0, 0);
                 }
         }
+        };
+        if constexpr (MODE == 0 && !DMA) {
+            // register-staged variants (d <= 32, d >= 80): one short branch per q-tile that rejoins before phase 2; these kernels
+            // sit at the VGPR limit and a second copy of phase 2 costs them more than the register copies at the join
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+                if (__any(trigq[qt])) rescale(qt);
+            phase2();
+            return false;
+        } else if constexpr (MODE == 0) {
+            if (any_trig) { rescale(0); rescale(1); phase2(); }
+            else phase2();
+            return false;
+        } else if constexpr (MODE == 1) {
+            if (any_trig) {
+                // the transposed V reads issued from inline asm above are still in flight and the compiler does not know it: were the
+                // fragments carried out of the loop as they are, it would be free to copy registers the LDS has not written yet
+                // (so they are retired here, and the finishing call reads the fragments again: nothing of them is live across the loop exit)
+                if constexpr (DMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                return true;
+            }
+            phase2();
+            return false;
+        } else {
+            if constexpr (DMA) issue_v_reads(sV);
+            rescale(0); rescale(1); phase2();
+            return false;
+        }
     };
+    using M0 = std::integral_constant<int, 0>;
 
     if constexpr (DMA) {
         constexpr int CPR = VROW / 8, VPW = 16 * CPR, NVI = (VPW + 63) / 64, NKI = 2;   // V chunks per row / per wave; DMA instructions per wave
@@ -421,18 +469,36 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         issue_tile(0, 0);
         if (ntile > 1) issue_tile(64, 1);
         int slot = 0;
-        for (int t = 0; t < ntile; ++t) {
-            // this wave's pieces of tile t have landed (tile t+1's NKI+NVI pieces may stay in flight); the barrier then makes the
-            // whole tile visible and tells everyone that slot (t+2)%3 == (t-1)%3 is no longer read
-            if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKI + NVI) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int nfull = p.Skv >> 6;
+        // Full tiles.  The inner loop is the common path only: scores, exponentials, P.V, with O accumulated in place.  A tile whose
+        // scores raise some query's running maximum leaves it unfinished (mode 1 returns true); the rescale and that tile's
+        // exp / P.V then run out here and the inner loop is entered again.  Kept inside the loop, the rescale's writes to O and to
+        // the Q fragments made the compiler hold every loop-carried register twice and copy them across on each tile.
+        int t = 0;
+        while (t < nfull) {
+            bool unfinished = false;
+            for (; t < nfull; ++t) {
+                // this wave's pieces of tile t have landed (tile t+1's NKI+NVI pieces may stay in flight); the barrier then makes the
+                // whole tile visible and tells everyone that slot (t+2)%3 == (t-1)%3 is no longer read
+                if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKI + NVI) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (t + 2 < ntile) issue_tile((t + 2) * 64, slot == 0 ? 2 : slot - 1);
+                if (tile(t * 64, slot, std::false_type{}, std::integral_constant<int, 1>{})) { unfinished = true; break; }
+                slot = slot == 2 ? 0 : slot + 1;
+            }
+            if (!unfinished) break;
+            (void)tile(t * 64, slot, std::false_type{}, std::integral_constant<int, 2>{});
+            slot = slot == 2 ? 0 : slot + 1;
+            ++t;
+        }
+        if (nfull < ntile) {   // the ragged last tile, peeled: with both tile bodies inside the loop the compiler kept every loop-carried
+                               // register (O, Q fragments) twice and copied them across on each iteration
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 2 < ntile) issue_tile((t + 2) * 64, slot == 0 ? 2 : slot - 1);
-            const int kv0 = t * 64;
-            if (kv0 + 64 > p.Skv) tile(kv0, slot, std::true_type{});   // block-uniform branch
-            else tile(kv0, slot, std::false_type{});
-            slot = slot == 2 ? 0 : slot + 1;
+            tile(nfull * 64, slot, std::true_type{}, M0{});
         }
     } else
     if (PREFETCH) {
@@ -453,8 +519,8 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             if (kv0 + 64 < p.Skv) store_tile(buf ^ 1);     // last read in the previous iteration, which ended with a barrier
             if (kv0 + 128 < p.Skv) load_tile(kv0 + 128);
             STAMP(0);
-            if (kv0 + 64 > p.Skv) tile(kv0, buf, std::true_type{});   // block-uniform branch
-            else tile(kv0, buf, std::false_type{});
+            if (kv0 + 64 > p.Skv) tile(kv0, buf, std::true_type{}, M0{});   // block-uniform branch
+            else tile(kv0, buf, std::false_type{}, M0{});
             STAMP(1);
             __syncthreads();
             STAMP(2);
@@ -474,8 +540,8 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             __syncthreads();  // everyone done reading the previous tile
             store_tile(0);
             __syncthreads();
-            if (kv0 + 64 > p.Skv) tile(kv0, 0, std::true_type{});   // block-uniform branch
-            else tile(kv0, 0, std::false_type{});
+            if (kv0 + 64 > p.Skv) tile(kv0, 0, std::true_type{}, M0{});   // block-uniform branch
+            else tile(kv0, 0, std::false_type{}, M0{});
         }
     }
     // finish: o[dt][qt][r] <-> d index 16*dt + 4*fg + r, q = q0 + 16*qt + fr
