@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const h
                 for (int j = 0; j < 4; ++j) {
                     const float4 t = abp[j];
                     float y0 = ((float)v[u][2 * j] + (float)vl[u][2 * j]) * t.x + t.y, y1 = ((float)v[u][2 * j + 1] + (float)vl[u][2 * j + 1]) * t.z + t.w;
-                    if (silu) { y0 = y0 / (1.0f + __expf(-y0)); y1 = y1 / (1.0f + __expf(-y1)); }
+                    if (silu) { y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0)); y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1)); }   // v_rcp_f32 (1 ulp), not the 11-instruction IEEE division
                     o[2 * j] = (half_t)y0; o[2 * j + 1] = (half_t)y1;
                 }
                 *(half8*)(Y + rw[u] * C + cc[u]) = o;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const half_t* X0, const h
                 const float a = rstd * gg[j];
                 const float xv = LO ? (float)v[u][j] + (float)vl[u][j] : (float)v[u][j];
                 float y = xv * a + (bb[j] - mean * a);   // same scale/shift form as the two-pass path
-                if (silu) y = y / (1.0f + __expf(-y));
+                if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
                 o[j] = (half_t)y;
             }
             *(half4n*)(Y + ((long long)nb * HW + px) * C + c) = o;
