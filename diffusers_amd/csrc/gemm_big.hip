@@ -19,6 +19,7 @@
 #include "gemm_common.h"
 
 #include <algorithm>
+#include <type_traits>
 
 #ifndef BIG_RG
 #define BIG_RG(LO) ((LO) ? 1 : 2)
@@ -299,6 +300,10 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             }
         }
         half_t* D = p.D + zD;
+        // the GELU form is chosen ONCE: with the test inside gelu_sel every value sat behind its own branch, and the rcp / exp latencies of
+        // one value could not be covered by the arithmetic of the next
+        auto geglu_rows = [&](auto tanh_tag) {
+        constexpr bool TANH = decltype(tanh_tag)::value;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
                 const int mt = mh * 4 + mq;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * gelu_sel(acc[nt][mt][1] + bvg[nt][0], p.gelu_tanh)),
-                                       (half_t)((acc[nt][mt][2] + bvv[nt][1]) * gelu_sel(acc[nt][mt][3] + bvg[nt][1], p.gelu_tanh))};
+                    const half2_t h = {(half_t)((acc[nt][mt][0] + bvv[nt][0]) * (TANH ? gelu_tanh_form(acc[nt][mt][1] + bvg[nt][0]) : gelu_erf(acc[nt][mt][1] + bvg[nt][0]))),
+                                       (half_t)((acc[nt][mt][2] + bvv[nt][1]) * (TANH ? gelu_tanh_form(acc[nt][mt][3] + bvg[nt][1]) : gelu_erf(acc[nt][mt][3] + bvg[nt][1])))};
                     *(half2_t*)(wlds + (mq * 16 + fr) * PITCH + (nt * 8 + 2 * fg) * 2) = h;
                 }
             }
@@ -326,6 +331,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+        };
+        if (p.gelu_tanh) geglu_rows(std::true_type{}); else geglu_rows(std::false_type{});
         return;
     }
     {   // EPI_STD, 32 rows (two row groups) at a time: fp32 in LDS so the residual is added before the single rounding.
