@@ -50,11 +50,11 @@ def symbol_key(name: str) -> str:
     base, targs = (m.group(1), m.group(2) or "") if m else (name, "")
     t = [a.strip() for a in targs.split(",")] if targs else []
     if base == "gemm_big_kernel" and len(t) >= 4:
-        return f"gemm_big_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, {t[3]}>"
+        return f"gemm_big_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, {t[3]}, LO>"
     if base == "gemm_midl_kernel" and len(t) >= 2:
-        return f"gemm_midl_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}>"
+        return f"gemm_midl_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, LO>"
     if base == "gemm_mid_kernel" and len(t) >= 3:
-        return f"gemm_mid_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}>"
+        return f"gemm_mid_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, LO>"
     if base == "gemm_mfma_kernel" and len(t) >= 3:
         return f"gemm_mfma_kernel<BM, BN, {t[2]}>"
     if base == "attn_mfma_kernel" and len(t) >= 2:
