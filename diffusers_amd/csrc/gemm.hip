@@ -269,6 +269,7 @@ bool gemm_big_supported(const GemmArgs& a);                                     
 int gemm_big_bn(const GemmArgs& a);
 bool gemm_mid_supported(const GemmArgs& a);                                        // gemm_mid.hip
 void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
+void launch_gemm_mid128(const LaunchCtx& ctx, GemmDev& p, int batch);
 void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 
 int gemm_npad(int N) { return (N % 160 == 0 || N % 128 == 0) ? N : round_up(N, 128); }
@@ -396,6 +397,23 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         }
     }
     static const int mid_env = getenv("SDE_MID") ? atoi(getenv("SDE_MID")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
+    static const int mid128_env = getenv("SDE_MID128") ? atoi(getenv("SDE_MID128")) : 1;   // tuning hook: 0 never, 1 heuristic
+    if (!ctx.force_naive && !ctx.force_big && !ctx.force_mid && a.taps == 1 && gemm_mid_supported(a)) {
+        // linears whose 256-row tiles leave the chip half empty (the 16x16 level, M = 4096 at batch 16): 128x160 tiles, loader waves,
+        // loads three K-tiles ahead.  The 4-wave 64x160 kernel they ran on moves (1/64 + 1/160) / (1/128 + 1/160) = 1.56x the bytes from
+        // L2 into LDS, and that path (~70 GB/s per CU, MI355X_MICROARCH.md) is what bounds these launches.
+        const int tiles256 = cdiv(a.M, 256) * (a.Npad / 160) * a.batch, tiles128 = cdiv(a.M, 128) * (a.Npad / 160) * a.batch;
+        // measured (M = 4096, N = 1280, us): K = 1280 27.9 -> 24.5, K = 2560 41.0 -> 38.1; K = 5120 stays on the 256x160 kernel with a
+        // 2-way split (58.3 against 65.7 here)
+        if (ctx.force_mid128 || (mid128_env && tiles256 < 192 && tiles128 >= 192 && (a.K >> 6) < 64)) {
+            {
+                ProfScope ps(ctx, prof_name("gemm_mfma_128x160", a, "H"), flops, bytes);
+                launch_gemm_mid128(ctx, p, a.batch);
+            }
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     if (!ctx.force_naive && mid_env && !ctx.force_big && gemm_mid_supported(a)) {
         // 8-wave 256x160 tiles with a 3-deep ring: the 32x32 / 16x16 UNet levels (one block per CU)
         const int tiles = cdiv(a.M, 256) * (a.Npad / 160) * a.batch, nk = a.K >> 6;

@@ -46,7 +46,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 #define MID_RG(LO) ((LO) ? 1 : 2)
 #endif
 // LO: split-fp16 residual / result (hi + lo pairs); its own instance so the plain epilogue keeps its register budget (gemm_big.hip)
-template <bool LO>
+template <bool LO, int SLICE = SMEM_BYTES / 8>
 __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT][MT], int m0, int n0, int ks, int z,
                                              int wid, int wr, int wc, int lane, int fr, int fg)
 {
@@ -68,7 +68,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
         return;
     }
     // EPI_STD through the wave's own LDS slice (see gemm_big.hip): fp32 staging, 16-byte row-order stores
-    char* const wlds = smem + wid * (SMEM_BYTES / 8);
+    char* const wlds = smem + wid * SLICE;
     const bool vec_ok = (p.ldd & 7) == 0;
     constexpr int PITCH = WN * 4 + 32, CH = WN / 8;
     constexpr int RG = MID_RG(LO);          // 16-row groups per step (gemm_big.hip: the split-fp16 instance takes one)
@@ -367,9 +367,21 @@ __global__ __launch_bounds__(512) void gemm_mid_kernel(GemmDev p)
 //   I1: A rows 128-255 (waves 4-7 finished reading tile t-1 during I0)                                  4
 //   I2: W rows, first 3 pieces                                                                          3
 //   I3: W rows, last 2 pieces; then wait until only tile t+2's 13 pieces are in flight (tile t+1 has landed)
-template <bool CONV, bool UPS, bool LO = false>
-__global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
+//
+// BM_ = 128 (linears of the 16x16 level, M = 4096: 256 tiles of 128x160 where 256-row tiles would fill half the chip and the 4-wave
+// 64x160 kernel moves 1.6x the bytes through the L2 -> LDS path, which is what bounds it): 4 compute waves (2 x 2, the same 64x80 wave
+// tile; waves 0-1 = group 0, waves 2-3 one barrier behind) + 4 loaders, and the smaller stage buys a 4-deep ring: loads run THREE
+// tiles ahead.  Same interval plan: I0 A rows 0-63 (read by group 0 only), I1 A rows 64-127, I2 / I3 the W rows.
+template <bool CONV, bool UPS, bool LO = false, int BM_ = 256>
+__global__ __launch_bounds__((BM_ / 32 + 4) * 64) void gemm_midl_kernel(GemmDev p)
 {
+    constexpr int NCW = BM_ / 32;                 // compute waves
+    constexpr int NQ = BM_ / 32;                  // A pieces (8 rows x 128 B) per loader and K-tile
+    constexpr int A_B = BM_ * 128, STG = A_B + BN * 128;
+    constexpr int NSTG = BM_ == 256 ? 3 : 4, DIST = NSTG - 1;   // ring depth; loads run DIST tiles ahead
+    constexpr int PP = NQ + 5;                    // pieces per loader and K-tile
+    static_assert(NSTG * STG <= 160 * 1024, "LDS");
+    constexpr int BM = BM_;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -390,18 +402,18 @@ __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
 #define BAR() do { FENCE(); __builtin_amdgcn_s_barrier(); FENCE(); } while (0)
 
-    if (wid >= 8) {
+    if (wid >= NCW) {
         // ================================================================ loader waves
-        const int lw = wid - 8;
+        const int lw = wid - NCW;
         const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A0 + z * p.sA), 0, OOB, RSRC_FLAGS);
         const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)((p.A1 ? p.A1 : p.A0) + z * p.sA), 0, OOB, RSRC_FLAGS);
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + z * p.sW), 0, OOB, RSRC_FLAGS);
         const int srow = lane >> 3;
         const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
         // A piece q = 2*j + i (j = 64-row part, i = 0/1): rows j*64 + (lw*2 + i)*8 + srow
-        unsigned a_off0[8], a_off1[8], a_mask[8];
+        unsigned a_off0[NQ], a_off1[NQ], a_mask[NQ];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < NQ; ++q) {
             const int m = m0 + (q >> 1) * 64 + (lw * 2 + (q & 1)) * 8 + srow;
             const bool ok = m < p.M;
             int pix = m;
@@ -453,7 +465,7 @@ __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
             stage_scalars();
         };
         auto issue_a = [&](int q, int buf) {
-            char* dst = smem + buf * STAGE + (q >> 1) * 8192 + (lw * 2 + (q & 1)) * 1024;
+            char* dst = smem + buf * STG + (q >> 1) * 8192 + (lw * 2 + (q & 1)) * 1024;
             unsigned voff = (st_second ? a_off1[q] : a_off0[q]) + (unsigned)st_add;
             if (CONV && UPS) {
                 const int ey = (a_mask[q] >> 9) & 1 ? st_ey1 : st_ey0;
@@ -465,51 +477,115 @@ __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
             else           __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
         };
         auto issue_w = [&](int i, int buf) {
-            char* dst = smem + buf * STAGE + A_BYTES + (lw * 5 + i) * 1024;
+            char* dst = smem + buf * STG + A_B + (lw * 5 + i) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, i * w_step + st_k0 * 2, 0, 0);
         };
         auto issue_all = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) issue_a(q, buf);
+            for (int q = 0; q < NQ; ++q) issue_a(q, buf);
 #pragma unroll
             for (int i = 0; i < 5; ++i) issue_w(i, buf);
         };
+        if constexpr (BM_ == 128) {
+            // one barrier per K-tile (see the compute waves below): barrier kt says "tile kt+1 has landed" to the compute waves and
+            // "nobody reads tile kt any more" to the loaders, who refill its slot with tile kt+4 straight away.
+#pragma unroll
+            for (int s = 0; s < NSTG; ++s) if (s < nk) { issue_all(s); stage_advance(); }
+            if (nk >= 4) wait_vmcnt<3 * PP>(); else if (nk == 3) wait_vmcnt<2 * PP>(); else if (nk == 2) wait_vmcnt<PP>(); else wait_vmcnt<0>();
+            BAR();
+            int cb = 0;
+            for (int kt = 0; kt < nk; ++kt) {
+                const int ahead = min(nk - 1, kt + 3) - (kt + 1);   // tiles after kt+1 that are in flight
+                if (ahead >= 2) wait_vmcnt<2 * PP>(); else if (ahead == 1) wait_vmcnt<PP>(); else wait_vmcnt<0>();
+                BAR();
+                if (kt + NSTG < nk) { issue_all(cb); stage_advance(); }
+                cb = cb == NSTG - 1 ? 0 : cb + 1;
+            }
+            return;
+        }
+        // prologue: the first DIST tiles; wait until tile 0 has landed (everything but the newer tiles' pieces)
         issue_all(0);
         stage_advance();
-        if (nk > 1) { issue_all(1); stage_advance(); wait_vmcnt<13>(); }
+        if (nk > 1) { issue_all(1); stage_advance(); }
+        if (DIST == 3 && nk > 2) { issue_all(2); stage_advance(); }
+        if (DIST == 3 && nk > 2) wait_vmcnt<2 * PP>();
+        else if (nk > 1) wait_vmcnt<PP>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         int cb = 0;
         for (int kt = 0; kt < nk; ++kt) {
-            const int nb_ = cb == 0 ? 2 : cb - 1;          // slot of tile kt+2 == slot of tile kt-1
-            const bool more2 = kt + 2 < nk;
-            if (more2) { issue_a(0, nb_); issue_a(1, nb_); issue_a(2, nb_); issue_a(3, nb_); }
+            const int nb_ = cb == 0 ? NSTG - 1 : cb - 1;   // slot of tile kt+DIST == slot of tile kt-1
+            const bool more2 = kt + DIST < nk;
+            if (more2) {
+#pragma unroll
+                for (int q = 0; q < NQ / 2; ++q) issue_a(q, nb_);
+            }
             BAR();
-            if (more2) { issue_a(4, nb_); issue_a(5, nb_); issue_a(6, nb_); issue_a(7, nb_); }
+            if (more2) {
+#pragma unroll
+                for (int q = NQ / 2; q < NQ; ++q) issue_a(q, nb_);
+            }
             BAR();
             if (more2) { issue_w(0, nb_); issue_w(1, nb_); issue_w(2, nb_); }
             BAR();
-            if (more2) { issue_w(3, nb_); issue_w(4, nb_); stage_advance(); wait_vmcnt<13>(); }
+            // leave only the tiles after kt+1 in flight: tile kt+1 has landed when the interval ends
+            if (more2) { issue_w(3, nb_); issue_w(4, nb_); stage_advance(); wait_vmcnt<(DIST - 1) * PP>(); }
+            else if (DIST == 3 && kt + 2 < nk) wait_vmcnt<PP>();
             else wait_vmcnt<0>();
             BAR();
-            cb = cb == 2 ? 0 : cb + 1;
+            cb = cb == NSTG - 1 ? 0 : cb + 1;
         }
         __builtin_amdgcn_s_barrier();   // the extra barrier of waves 4-7
         return;
     }
 
     // ==================================================================== compute waves
-    const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2;
+    const int wr = wid >> 1, wc = wid & 1, grp = wid >= NCW / 2;
     const int fr = lane & 15, fg = lane >> 4;
     const int swz0 = ((fg) ^ (fr & 7)) << 4, swz1 = ((4 + fg) ^ (fr & 7)) << 4;
     const int a_rd0 = (wr * 64 + fr) * 128 + swz0, a_rd1 = (wr * 64 + fr) * 128 + swz1;
-    const int b_rd0 = A_BYTES + (wc * WN + fr) * 128 + swz0, b_rd1 = A_BYTES + (wc * WN + fr) * 128 + swz1;
+    const int b_rd0 = A_B + (wc * WN + fr) * 128 + swz0, b_rd1 = A_B + (wc * WN + fr) * 128 + swz1;
     floatx4 acc[NT][MT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < MT; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
     half8 bf[NT], af[MT];
+    if constexpr (BM_ == 128) {
+        // One compute wave per SIMD: nothing to ping-pong with, so each wave pipelines by itself.  Two fragment sets; the LDS reads of
+        // the next k-half are issued in front of the 20 MFMAs of the current one, and a K-tile costs one barrier instead of four.
+        half8 bg[NT], ag[MT];
+#define LOAD_SET(B_, A_, base, bo, ao)                                                                   \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) B_[nt] = *(const half8*)((base) + (bo) + nt * 2048); \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) A_[mt] = *(const half8*)((base) + (ao) + mt * 2048);
+#define MFMA_SET(B_, A_)                                                                                 \
+        __builtin_amdgcn_s_setprio(1);                                                                   \
+        _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                 \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                             \
+                acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(B_[nt], A_[mt], acc[nt][mt], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);
+        BAR();                                   // tile 0 has landed
+        LOAD_SET(bf, af, smem, b_rd0, a_rd0)
+        int cb = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* cur = smem + cb * STG;
+            cb = cb == NSTG - 1 ? 0 : cb + 1;
+            LOAD_SET(bg, ag, cur, b_rd1, a_rd1)
+            FENCE();
+            MFMA_SET(bf, af)
+            FENCE();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's reads of tile kt are complete
+            BAR();
+            if (kt + 1 < nk) { LOAD_SET(bf, af, smem + cb * STG, b_rd0, a_rd0) }
+            FENCE();
+            MFMA_SET(bg, ag)
+            FENCE();
+        }
+#undef LOAD_SET
+#undef MFMA_SET
+        mid_epilogue<LO, NSTG * STG / NCW>(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
+        return;
+    }
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
 #define LOAD_FRAGS(bo, ao)                                                                            \
@@ -523,7 +599,7 @@ __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
     __builtin_amdgcn_s_setprio(0);
     int cb = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const char* cur = smem + cb * STAGE;
+        const char* cur = smem + cb * STG;
         LOAD_FRAGS(b_rd0, a_rd0)
         BAR();
         MFMA_ALL()
@@ -532,14 +608,14 @@ __global__ __launch_bounds__(768) void gemm_midl_kernel(GemmDev p)
         BAR();
         MFMA_ALL()
         BAR();
-        cb = cb == 2 ? 0 : cb + 1;
+        cb = cb == NSTG - 1 ? 0 : cb + 1;
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7
 #undef LOAD_FRAGS
 #undef MFMA_ALL
 #undef BAR
 #undef FENCE
-    mid_epilogue<LO>(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
+    mid_epilogue<LO, NSTG * STG / NCW>(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -580,6 +656,25 @@ static void launch_midl_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
     auto kern = gemm_midl_kernel<CONV, UPS>;
     allow_dynamic_lds((const void*)kern, SMEM_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(768), SMEM_BYTES, ctx.stream, p);
+}
+
+// 128x160 tiles (linears only): 4 compute + 4 loader waves, 4-deep ring
+void launch_gemm_mid128(const LaunchCtx& ctx, GemmDev& p, int batch)
+{
+    constexpr int BM128 = 128, SMEM128 = 4 * (BM128 * 128 + BN * 128);   // 147,456 B
+    p.nbm = cdiv(p.M, BM128);
+    p.nbn = p.Npad / BN;
+    p.splitk = 1; p.ws = nullptr;
+    dim3 grid(p.nbm * p.nbn, 1, batch);
+    if (p.Rlo || p.Dlo) {
+        auto kern = gemm_midl_kernel<false, false, true, BM128>;
+        allow_dynamic_lds((const void*)kern, SMEM128);
+        hipLaunchKernelGGL(kern, grid, dim3(512), SMEM128, ctx.stream, p);
+    } else {
+        auto kern = gemm_midl_kernel<false, false, false, BM128>;
+        allow_dynamic_lds((const void*)kern, SMEM128);
+        hipLaunchKernelGGL(kern, grid, dim3(512), SMEM128, ctx.stream, p);
+    }
 }
 
 void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv)

@@ -16,6 +16,7 @@ struct LaunchCtx {
     const half_t* zeros = nullptr;  // >= 256 B of device zeros (source for padded taps / tail rows)
     bool force_naive = false;
     bool force_mid = false;         // test hook: take the 8-wave 256x160 kernel whenever it supports the problem
+    bool force_mid128 = false;      // test hook: take the 128x160 loader-wave kernel (linears) whenever it supports the problem
     bool force_big = false;         // test hook: take the 8-wave 256x320 kernel whenever it supports the problem
     float* splitk_ws = nullptr;     // fp32 partial-tile workspace for split-K GEMMs (null: split-K off)
     size_t splitk_ws_bytes = 0;

@@ -113,6 +113,35 @@ def test_conv_big_tile_kernel(engine, case):
     assert rel_l2(big, ref) < 2e-3
 
 
+MID128_CASES = [
+    # NB, H, W, Cin, Cout -- linears on the 128x160 loader-wave kernel (4-deep ring, loads three K-tiles ahead)
+    (1, 16, 16, 64, 160),       # one K-tile: prologue only
+    (1, 16, 16, 128, 320),      # two K-tiles
+    (1, 20, 20, 192, 160),      # three K-tiles (the prologue fills the ring), ragged M (400 rows)
+    (1, 16, 24, 256, 320),      # four: the first load issued inside the loop, into slot 3
+    (2, 16, 16, 320, 480),      # five: the ring wraps
+    (1, 30, 30, 384, 160),      # six, ragged M
+    (16, 16, 16, 1280, 1280),   # the 16x16 UNet level at batch 16: 256 tiles, 20 K-tiles
+    (4, 16, 16, 2560, 1280),    # 40 K-tiles
+    (1, 24, 24, 704, 160),      # eleven K-tiles, ragged M (576 rows = 4.5 tiles)
+]
+
+
+@pytest.mark.parametrize("case", MID128_CASES)
+def test_linear_mid128_kernel(engine, case):
+    NB, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = run_conv(engine, 4, x, w, b, 1, 1, 0)
+    xh = torch.from_numpy(x).half().float().reshape(-1, Cin)
+    ref = (xh.double() @ torch.from_numpy(w).half().double().reshape(Cout, Cin).T + torch.from_numpy(b).double()).float().numpy().reshape(NB, H, W, Cout)
+    assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
+    # the heuristic must agree with it whatever kernel it picks
+    assert rel_l2(run_conv(engine, 0, x, w, b, 1, 1, 0), ref) < 2e-3
+
+
 MID_CASES = [
     # NB, H, W, Cin, Cout, k, stride, ups -- shapes the 8-wave 256x160 kernel accepts (Cout % 160 == 0, Cin % 64 == 0)
     (1, 32, 32, 320, 320, 3, 1, 0),     # 1024 rows: 4 row tiles x 2 column tiles, 45 K-tiles (3-deep ring wraps many times)

@@ -32,8 +32,8 @@ def kernel_class(name: str) -> str:
         nt = t[2] if len(t) > 2 else "5"
         tile = "256x320" if nt == "5" else "256x256"
         return ("conv3x3_mfma_" if conv else "gemm_mfma_") + tile
-    if base == "gemm_midl_kernel":      # loader-wave variant: the 3x3 convolutions of the 256x160 class
-        return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + "256x160"
+    if base == "gemm_midl_kernel":      # loader-wave variant: the 3x3 convolutions of the 256x160 class; <.., 128>: the 128x160 linears
+        return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + ("128x160" if len(t) > 3 and t[3] == "128" else "256x160")
     if base == "gemm_mid_kernel":
         return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + "256x160"
     if base == "gemm_mfma_kernel":
@@ -52,7 +52,7 @@ def symbol_key(name: str) -> str:
     if base == "gemm_big_kernel" and len(t) >= 4:
         return f"gemm_big_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, {t[3]}, LO>"
     if base == "gemm_midl_kernel" and len(t) >= 2:
-        return f"gemm_midl_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, LO>"
+        return f"gemm_midl_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, LO, {t[3] if len(t) > 3 else '256'}>"
     if base == "gemm_mid_kernel" and len(t) >= 3:
         return f"gemm_mid_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, LO>"
     if base == "gemm_mfma_kernel" and len(t) >= 3:
