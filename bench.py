@@ -109,7 +109,7 @@ ROCPROF_SYMBOL = {
     "gemm_mfma_256x320": "gemm_big_kernel<false, false, 5, 0, LO>", "gemm_geglu_mfma_256x320": "gemm_big_kernel<false, false, 5, 0, LO>",
     "gemm_mfma_256x256": "gemm_big_kernel<false, false, 4, 0, LO>",
     "conv3x3_mfma_256x160": "gemm_midl_kernel<true, UPS, LO, 256>", "gemm_mfma_256x160": "gemm_mid_kernel<false, false, 0, LO>",
-    "gemm_mfma_128x160": "gemm_midl_kernel<false, false, LO, 128>",
+    "gemm_mfma_ldw128": "gemm_midl_kernel<false, false, LO, 128>", "conv3x3_mfma_halo": "gemm_midh_kernel<LO>",
     "conv3x3_mfma": "gemm_mfma_kernel<BM, BN, true>", "gemm_mfma": "gemm_mfma_kernel<BM, BN, false>",
     "splitk_reduce": "splitk_reduce_kernel",
 }

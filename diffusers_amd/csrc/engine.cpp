@@ -1113,7 +1113,7 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
         EngineLock lk(e);
         engine_activate(e);
-        LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3; ctx.force_mid128 = naive == 4;   // 0 fast, 1 plain, 2 / 3 / 4 force the 256x320 / 256x160 / 128x160 kernel
+        LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3; ctx.force_mid128 = naive == 4; ctx.force_midh = naive == 5;   // 0 fast, 1 plain, 2 / 3 / 4 / 5 force the 256x320 / 256x160 / 128x160 / halo kernel
         const int taps = ksize * ksize;
         // upsample: 1 = nearest 2x; 2 = 2x cropped to (2*Hi - 1) x (2*Wi - 1), the UNet's upsample-to-skip-size on odd latents
         // upsample == 3: not an upsample -- the VAE encoder's downsampler, pad (0,1,0,1) + a pad-0 stride-2 window (GemmArgs::coff = 1)

@@ -270,6 +270,8 @@ int gemm_big_bn(const GemmArgs& a);
 bool gemm_mid_supported(const GemmArgs& a);                                        // gemm_mid.hip
 void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 void launch_gemm_mid128(const LaunchCtx& ctx, GemmDev& p, int batch);
+bool gemm_midh_supported(const GemmArgs& a);
+void launch_gemm_midh(const LaunchCtx& ctx, GemmDev& p);
 void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 
 int gemm_npad(int N) { return (N % 160 == 0 || N % 128 == 0) ? N : round_up(N, 128); }
@@ -376,7 +378,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
     const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (1 + (a.R ? 1 : 0) + (a.Rlo ? 1 : 0) + (a.Dlo ? 1 : 0))) * 2.0 * a.batch;
     static const int big_env = getenv("SDE_BIG") ? atoi(getenv("SDE_BIG")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
-    if (!ctx.force_naive && big_env && !ctx.force_mid && gemm_big_supported(a)) {
+    if (!ctx.force_naive && big_env && !ctx.force_mid && !ctx.force_midh && gemm_big_supported(a)) {
         // 8-wave 256x320 tiles, one block per CU: worth it once the grid (with split-K on long K) covers most of the chip
         const int tiles = cdiv(a.M, 256) * (a.Npad / gemm_big_bn(a)) * a.batch, nk = a.K >> 6;
         int sk = 1;
@@ -407,7 +409,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         // 2-way split (58.3 against 65.7 here)
         if (ctx.force_mid128 || (mid128_env && tiles256 < 192 && tiles128 >= 192 && (a.K >> 6) < 64)) {
             {
-                ProfScope ps(ctx, prof_name("gemm_mfma_128x160", a, "H"), flops, bytes);
+                ProfScope ps(ctx, prof_name("gemm_mfma_ldw128", a, "H"), flops, bytes);
                 launch_gemm_mid128(ctx, p, a.batch);
             }
             HIP_CHECK(hipGetLastError());
@@ -425,6 +427,20 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             sk = std::min(std::min((256 + tiles / 2) / tiles, nk / 16), 8);
             if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;
+        }
+        // 3x3 stride-1 convolutions over whole 16 x 16 patches: the halo kernel (input staged once per 64-channel chunk, not per tap)
+        static const int midh_env = getenv("SDE_MIDH") ? atoi(getenv("SDE_MIDH")) : 1;   // tuning hook: 0 never, 1 whenever supported
+        const bool halo = !ctx.force_mid && (midh_env || ctx.force_midh) && gemm_midh_supported(a);
+        if (halo && (mid_env == 2 || ctx.force_midh || tiles * sk >= 192)) {
+            sk = std::min(sk, a.K / 576);
+            p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
+            {
+                ProfScope ps(ctx, prof_name("conv3x3_mfma_halo", a, "P"), flops, bytes);
+                launch_gemm_midh(ctx, p);
+            }
+            if (sk > 1) launch_splitk_reduce(ctx, p);
+            HIP_CHECK(hipGetLastError());
+            return;
         }
         if (mid_env == 2 || ctx.force_mid || tiles * sk >= 192) {
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;

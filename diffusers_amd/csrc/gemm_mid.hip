@@ -17,6 +17,8 @@
 #include "gemm_common.h"
 
 #include <algorithm>
+#include <type_traits>
+#include <utility>
 
 namespace {
 constexpr int BM = 256, BN = 160, WN = 80, NT = 5, MT = 4;
@@ -46,17 +48,19 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 #define MID_RG(LO) ((LO) ? 1 : 2)
 #endif
 // LO: split-fp16 residual / result (hi + lo pairs); its own instance so the plain epilogue keeps its register budget (gemm_big.hip)
-template <bool LO, int SLICE = SMEM_BYTES / 8>
+// PATCH: the tile's 256 rows are a 16 x 16 patch of output pixels (halo kernel below): tile row r is pixel m0 + (r >> 4) * Wo + (r & 15)
+template <bool LO, int SLICE = SMEM_BYTES / 8, bool PATCH = false>
 __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT][MT], int m0, int n0, int ks, int z,
                                              int wid, int wr, int wc, int lane, int fr, int fg)
 {
     // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
     const long long zD = z * p.sD, zR = z * p.sR;
+    auto rowm = [&](int r) { return PATCH ? m0 + (r >> 4) * p.Wo + (r & 15) : m0 + r; };
     if (p.splitk > 1) {
         float* ws = p.ws + (long long)ks * p.M * p.Npad;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int m = m0 + wr * 64 + mt * 16 + fr;
+            const int m = rowm(wr * 64 + mt * 16 + fr);
             if (m < p.M) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
@@ -92,7 +96,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int id = min(lane + 64 * i, NCH - 1), row = id / CH, ch = id - row * CH;
-                const int m = min(m0 + wr * 64 + ms * (16 * RG) + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
+                const int m = min(rowm(wr * 64 + ms * (16 * RG) + row), p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
                 if (LO || rvec_ok) rr[i] = *(const half8*)(R + (long long)m * p.ldr + n);
                 else for (int e = 0; e < 8; ++e) rr[i][e] = R[(long long)m * p.ldr + n + e];
                 if constexpr (LO) if (Rlo) {
@@ -116,7 +120,7 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int id = lane + 64 * i, idc = min(id, NCH - 1), row = idc / CH, ch = idc - row * CH;
-            const int m = m0 + wr * 64 + ms * (16 * RG) + row, n = n0 + wc * WN + ch * 8;
+            const int m = rowm(wr * 64 + ms * (16 * RG) + row), n = n0 + wc * WN + ch * 8;
             const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
             const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             half8 v, vl;
@@ -618,6 +622,190 @@ __global__ __launch_bounds__((BM_ / 32 + 4) * 64) void gemm_midl_kernel(GemmDev 
     mid_epilogue<LO, NSTG * STG / NCW>(p, smem, acc, m0, n0, ks, z, wid, wr, wc, lane, fr, fg);
 }
 
+// ------------------------------------------------------------------------------------------ halo variant (3x3, stride 1)
+// The implicit GEMM above fetches every input pixel nine times, once per tap, and the L2 -> LDS path (~70 GB/s per CU) is what the
+// 256x160 convolutions run against: 53 KB per K-tile = 0.76 us where the 40 MFMAs per wave need 0.53.  Here a tile is a 16 x 16 PATCH
+// of output pixels of one image, and the 18 x 18 input halo of one 64-channel chunk is staged ONCE (324 rows of 128 B) and read by
+// all nine taps at row offset dy * 18 + dx: 4.6 KB of A per K-tile instead of 32 KB, 25 KB per K-tile in all.
+//   * K order is the other kernels' (chunk, tap, 64 channels): same weight buffer.
+//   * LDS: 2 halo buffers x 352 rows (44 pieces of 8 rows; rows >= 324 and out-of-image rows are zero-filled by the range check)
+//     + 3 W stages x 160 rows = 151,552 B.  Same XOR swizzle, keyed on the halo row.
+//   * 8 compute waves exactly as gemm_midl_kernel (64 x 80 wave tiles, four barriers per K-tile, waves 4-7 one barrier behind): a
+//     wave's 64 rows are four patch rows of 16 pixels.  4 loader waves, at most two pieces per interval each: the NEXT chunk's halo
+//     (11 pieces per loader) in interval 0 of taps 1-7, W of tile t+2 (5 pieces) in intervals 1-3.  The counted wait at the end of a
+//     K-tile leaves only that tile's own issues in flight, so W of tile t+1 has landed and, by the end of tap 8, the whole halo.
+//   * Split-K splits at chunk boundaries.
+namespace {
+constexpr int H_ROWS = 352, H_BYTES = H_ROWS * 128;   // 45,056 B per halo buffer
+constexpr int H_PIECES = 11;                          // halo pieces per loader wave
+constexpr int W_STG = BN * 128;                       // 20,480 B
+constexpr int H_SMEM = 2 * H_BYTES + 3 * W_STG;       // 151,552 B
+// pieces of the next chunk's halo issued at each tap, in interval 0: none at tap 0 (waves 4-7 are still reading that buffer) and none at
+// tap 8 (a tile's own issues are only known to have landed one tile later)
+constexpr int halo_cnt(int tap) { return tap == 0 || tap == 8 ? 0 : (tap <= 4 ? 2 : 1); }   // 0,2,2,2,2,1,1,1,0
+constexpr int halo_first(int tap) { return tap <= 4 ? 2 * (tap - 1) : 3 + tap; }            // -,0,2,4,6,8,9,10,-
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+}  // namespace
+
+template <bool LO>
+__global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int nwg = p.nbm * p.nbn;
+    int bid = blockIdx.x;
+    {
+        int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = p.colmajor ? bid % p.nbm : bid / p.nbn, tn = p.colmajor ? bid / p.nbm : bid - (bid / p.nbn) * p.nbn;
+    const int npx = p.Wo >> 4, ppi = (p.Ho >> 4) * npx;         // patches per row / per image
+    const int img = tm / ppi, pr = tm - img * ppi;
+    const int Y0 = (pr / npx) << 4, X0 = (pr - (pr / npx) * npx) << 4;
+    const int n0 = tn * BN;
+    const int nch = p.K / 576;                                   // 64-channel chunks
+    const int ks = blockIdx.y;
+    const int c0 = (int)((long long)nch * ks / p.splitk), c1 = (int)((long long)nch * (ks + 1) / p.splitk);
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define BAR() do { FENCE(); __builtin_amdgcn_s_barrier(); FENCE(); } while (0)
+    char* const wbase = smem + 2 * H_BYTES;
+
+    if (wid >= 8) {
+        // ================================================================ loader waves
+        const int lw = wid - 8;
+        const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A0, 0, OOB, RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A1 ? p.A1 : p.A0), 0, OOB, RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, OOB, RSRC_FLAGS);
+        const int srow = lane >> 3;
+        const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
+        // halo piece j of this loader: rows (lw + 4j) * 8 + srow of the 18 x 18 halo (row h = hy * 18 + hx)
+        unsigned hpix[H_PIECES], hmask = 0;
+#pragma unroll
+        for (int j = 0; j < H_PIECES; ++j) {
+            const int h = (lw + 4 * j) * 8 + srow;
+            const int hy = h / 18, hx = h - hy * 18;
+            const int iy = Y0 - 1 + hy, ix = X0 - 1 + hx;
+            const bool ok = h < 324 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            hpix[j] = ok ? (unsigned)((img * p.Hi + iy) * p.Wi + ix) : 0u;
+            hmask |= (ok ? 1u : 0u) << j;
+        }
+        auto issue_halo = [&](int j, int c, int hb) {
+            const int cc = c << 6;
+            const bool second = cc >= p.C0;
+            const unsigned ld2 = (unsigned)((second ? p.lda1 : p.lda0) * 2);
+            unsigned voff = hpix[j] * ld2 + lchunk16 + (unsigned)((second ? cc - p.C0 : cc) * 2);
+            voff = (hmask >> j) & 1u ? voff : OOB;
+            char* dst = smem + hb * H_BYTES + (lw + 4 * j) * 1024;
+            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, LDS_PTR(dst), 16, voff, 0, 0, 0);
+            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
+        };
+        const unsigned w_off = (unsigned)((n0 + lw * 40 + srow) * p.K) * 2u + lchunk16;
+        const int w_step = 8 * p.K * 2;
+        int st_k0 = c0 * 576;
+        auto issue_w = [&](int i, int slot) {
+            char* dst = wbase + slot * W_STG + (lw * 5 + i) * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, i * w_step + st_k0 * 2, 0, 0);
+        };
+        // prologue: the first chunk's halo, W of tiles 0 and 1 (a chunk is nine tiles: both exist)
+#pragma unroll
+        for (int j = 0; j < H_PIECES; ++j) issue_halo(j, c0, 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) issue_w(i, 0);
+        st_k0 += 64;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) issue_w(i, 1);
+        st_k0 += 64;
+        wait_vmcnt<5>();
+        __builtin_amdgcn_s_barrier();
+        int hb = 0;
+        for (int c = c0; c < c1; ++c) {
+            const bool next = c + 1 < c1;
+            static_for<9>([&](auto tap_) {
+                constexpr int tap = decltype(tap_)::value;
+                const bool more2 = next || tap < 7;              // tile + 2 exists
+                const int slot = (tap + 2) % 3;                  // == slot of tile - 1
+                // at most two pieces per interval: an LDS-DMA costs its issuing wave 100-150 cycles, and an interval is 20 MFMAs (320)
+                if (next) {
+#pragma unroll
+                    for (int q = 0; q < halo_cnt(tap); ++q) issue_halo(halo_first(tap) + q, c + 1, hb ^ 1);
+                }
+                BAR();
+                if (more2) { issue_w(0, slot); issue_w(1, slot); }
+                BAR();
+                if (more2) { issue_w(2, slot); issue_w(3, slot); }
+                BAR();
+                if (more2) { issue_w(4, slot); st_k0 += 64; }
+                // in flight afterwards: this tile's own issues only (the halo pieces above, W of tile + 2)
+                if (more2) { if (next) wait_vmcnt<5 + halo_cnt(tap)>(); else wait_vmcnt<5>(); }
+                else wait_vmcnt<0>();
+                BAR();
+            });
+            hb ^= 1;
+        }
+        __builtin_amdgcn_s_barrier();   // the extra barrier of waves 4-7
+        return;
+    }
+
+    // ==================================================================== compute waves
+    const int wr = wid >> 1, wc = wid & 1, grp = wid >> 2;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int swz0 = ((fg) ^ (fr & 7)) << 4, swz1 = ((4 + fg) ^ (fr & 7)) << 4;
+    const int b_rd0 = (wc * WN + fr) * 128 + swz0, b_rd1 = (wc * WN + fr) * 128 + swz1;
+    const int hrow0 = wr * 4 * 18 + fr;          // halo row of this lane's pixel in patch row wr*4, tap (0,0)
+    floatx4 acc[NT][MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < MT; ++b) acc[a][b] = floatx4{0.f, 0.f, 0.f, 0.f};
+    half8 bf[NT], af[MT];
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // waves 4-7 run one barrier behind
+#define LOAD_FRAGS_H(bo, kc, tapoff)                                                                  \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(curw + (bo) + nt * 2048);  \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
+        const int h_ = hr + mt * 18 + (tapoff);                                                       \
+        af[mt] = *(const half8*)(curh + (h_ << 7) + ((((kc) ^ h_) & 7) << 4));                         \
+    }
+#define MFMA_ALL()                                                                                    \
+    __builtin_amdgcn_s_setprio(1);                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                  \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                              \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[nt], af[mt], acc[nt][mt], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+    int hb = 0;
+    for (int c = c0; c < c1; ++c) {
+        const char* curh = smem + hb * H_BYTES;
+        // the 72 fragment addresses of a chunk do not depend on the chunk: left alone the compiler hoists them all out of the loop and
+        // spills them.  Three VALU instructions per read are cheaper than a scratch reload.
+        int hr = hrow0;
+        asm volatile("" : "+v"(hr));
+        static_for<9>([&](auto tap_) {
+            constexpr int tap = decltype(tap_)::value;
+            const char* curw = wbase + (tap % 3) * W_STG;
+            constexpr int tapoff = (tap / 3) * 18 + tap % 3;
+            LOAD_FRAGS_H(b_rd0, fg, tapoff)
+            BAR();
+            MFMA_ALL()
+            BAR();
+            LOAD_FRAGS_H(b_rd1, 4 + fg, tapoff)
+            BAR();
+            MFMA_ALL()
+            BAR();
+        });
+        hb ^= 1;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the extra barrier of waves 4-7
+#undef LOAD_FRAGS_H
+#undef MFMA_ALL
+#undef BAR
+#undef FENCE
+    const int pbase = (img * p.Ho + Y0) * p.Wo + X0;
+    mid_epilogue<LO, H_SMEM / 8, true>(p, smem, acc, pbase, n0, ks, 0, wid, wr, wc, lane, fr, fg);
+}
+
 // ------------------------------------------------------------------------------------------ host side
 bool gemm_big_supported(const GemmArgs& a);   // gemm_big.hip: shared operand rules
 
@@ -656,6 +844,32 @@ static void launch_midl_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
     auto kern = gemm_midl_kernel<CONV, UPS>;
     allow_dynamic_lds((const void*)kern, SMEM_BYTES);
     hipLaunchKernelGGL(kern, grid, dim3(768), SMEM_BYTES, ctx.stream, p);
+}
+
+// 3x3 stride-1 convolutions on whole 16 x 16 output patches: the halo kernel
+bool gemm_midh_supported(const GemmArgs& a)
+{
+    if (a.taps != 9 || a.stride != 1 || a.ups || a.coff || a.batch != 1) return false;
+    if (a.Ho != a.Hi || a.Wo != a.Wi || (a.Ho & 15) || (a.Wo & 15) || a.M % (a.Ho * a.Wo)) return false;
+    if (a.K % 576) return false;
+    return gemm_mid_supported(a);
+}
+
+void launch_gemm_midh(const LaunchCtx& ctx, GemmDev& p)
+{
+    p.nbm = p.M / BM;
+    p.nbn = p.Npad / BN;
+    SDE_REQUIRE(p.splitk >= 1 && p.splitk <= p.K / 576, SDE_ERR_INVALID_ARGUMENT, "launch_gemm_midh: more split-K ways than 64-channel chunks");
+    dim3 grid(p.nbm * p.nbn, p.splitk, 1);
+    if (p.Rlo || p.Dlo) {
+        auto kern = gemm_midh_kernel<true>;
+        allow_dynamic_lds((const void*)kern, H_SMEM);
+        hipLaunchKernelGGL(kern, grid, dim3(768), H_SMEM, ctx.stream, p);
+    } else {
+        auto kern = gemm_midh_kernel<false>;
+        allow_dynamic_lds((const void*)kern, H_SMEM);
+        hipLaunchKernelGGL(kern, grid, dim3(768), H_SMEM, ctx.stream, p);
+    }
 }
 
 // 128x160 tiles (linears only): 4 compute + 4 loader waves, 4-deep ring

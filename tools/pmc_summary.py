@@ -32,10 +32,12 @@ def kernel_class(name: str) -> str:
         nt = t[2] if len(t) > 2 else "5"
         tile = "256x320" if nt == "5" else "256x256"
         return ("conv3x3_mfma_" if conv else "gemm_mfma_") + tile
-    if base == "gemm_midl_kernel":      # loader-wave variant: the 3x3 convolutions of the 256x160 class; <.., 128>: the 128x160 linears
-        return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + ("128x160" if len(t) > 3 and t[3] == "128" else "256x160")
+    if base == "gemm_midl_kernel":      # loader-wave variant: the 3x3 convolutions of the 256x160 class; <.., 128>: the 128x160 linears, class gemm_mfma_ldw128
+        return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + ("ldw128" if len(t) > 3 and t[3] == "128" else "256x160")
     if base == "gemm_mid_kernel":
         return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + "256x160"
+    if base == "gemm_midh_kernel":
+        return "conv3x3_mfma_halo"
     if base == "gemm_mfma_kernel":
         conv = len(t) > 2 and t[2] == "true"
         return ("conv3x3_mfma_" if conv else "gemm_mfma_") + f"{t[0]}x{t[1]}" if len(t) > 1 else "gemm_mfma"
@@ -55,6 +57,8 @@ def symbol_key(name: str) -> str:
         return f"gemm_midl_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, LO, {t[3] if len(t) > 3 else '256'}>"
     if base == "gemm_mid_kernel" and len(t) >= 3:
         return f"gemm_mid_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, LO>"
+    if base == "gemm_midh_kernel":
+        return "gemm_midh_kernel<LO>"
     if base == "gemm_mfma_kernel" and len(t) >= 3:
         return f"gemm_mfma_kernel<BM, BN, {t[2]}>"
     if base == "attn_mfma_kernel" and len(t) >= 2:
