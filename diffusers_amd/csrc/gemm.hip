@@ -290,7 +290,11 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     {
         static const int cm_env = getenv("SDE_COLMAJOR") ? atoi(getenv("SDE_COLMAJOR")) : -1;   // tuning hook
         const double bytesA = (double)a.M * (a.C0 + a.C1) * 2.0 / (a.stride * a.stride) * (a.ups ? 0.25 : 1.0), bytesW = (double)a.Npad * a.K * 2.0;
-        p.colmajor = cm_env >= 0 ? cm_env : (bytesW > 4.0 * bytesA ? 1 : 0);   // measured: only the 8x8 level gains (3-4 %); near the break-even it is a wash
+        // Whichever operand is larger stays behind one L2.  In time only the 8x8 level gains (3-4 %) and near the break-even it is a wash,
+        // but the fabric traffic follows the model: 16x16-level 3x3 convs (W = 29.5 / 59 MB, A = 10.5 / 21 MB) fetch 185 MB per launch
+        // with column tiles fastest and 85 MB with row tiles fastest (FETCH_SIZE, raw); the 32x32 level (A > W) 66 against 80 MB.
+        static const double cm_ratio = getenv("SDE_COLMAJOR_RATIO") ? atof(getenv("SDE_COLMAJOR_RATIO")) : 1.0;   // tuning hook
+        p.colmajor = cm_env >= 0 ? cm_env : (bytesW > cm_ratio * bytesA ? 1 : 0);
     }
     return p;
 }
