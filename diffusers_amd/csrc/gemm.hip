@@ -382,7 +382,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
     const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (1 + (a.R ? 1 : 0) + (a.Rlo ? 1 : 0) + (a.Dlo ? 1 : 0))) * 2.0 * a.batch;
     static const int big_env = getenv("SDE_BIG") ? atoi(getenv("SDE_BIG")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
-    if (!ctx.force_naive && big_env && !ctx.force_mid && !ctx.force_midh && gemm_big_supported(a)) {
+    if (!ctx.force_naive && big_env && !ctx.force_mid && !ctx.force_midh && !ctx.force_mid128 && gemm_big_supported(a)) {
         // 8-wave 256x320 tiles, one block per CU: worth it once the grid (with split-K on long K) covers most of the chip
         const int tiles = cdiv(a.M, 256) * (a.Npad / gemm_big_bn(a)) * a.batch, nk = a.K >> 6;
         int sk = 1;
