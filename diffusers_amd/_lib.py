@@ -107,6 +107,7 @@ SYMBOLS = {
     "sde_profile_get": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
     "sde_synchronize": (_i, [_vp]),
     "sde_test_conv": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sde_test_conv_res": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "sde_test_attention": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
 }
 

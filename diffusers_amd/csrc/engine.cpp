@@ -1147,6 +1147,51 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
     });
 }
 
+sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin, const float* w, const float* bias, int Cout,
+                             int ksize, const float* residual, int split, float* out)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && x && w && out && residual, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
+        EngineLock lk(e);
+        engine_activate(e);
+        LaunchCtx ctx = e->ctx; ctx.f32 = false;
+        ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3; ctx.force_mid128 = naive == 4; ctx.force_midh = naive == 5;
+        const int taps = ksize * ksize;
+        const size_t nx = (size_t)NB * Hi * Wi * Cin, nw = (size_t)Cout * Cin * taps, no = (size_t)NB * Hi * Wi * Cout;
+        const int Npad = gemm_npad(Cout), K = taps * Cin;
+        // the residual as fp16 hi (+ lo): split on the host, the way a producer's epilogue would have left it
+        std::vector<half_t> rhi(no), rlo(no);
+        for (size_t i = 0; i < no; ++i) { rhi[i] = (half_t)residual[i]; rlo[i] = (half_t)(residual[i] - (float)rhi[i]); }
+        DevBuf dxf, dxh, dwf, dwh, dbias, doh, dol, drh, drl;
+        dxf.ensure(nx * 4); dxh.ensure(nx * 2); dwf.ensure(nw * 4); dwh.ensure((size_t)Npad * K * 2); doh.ensure(no * 2); dol.ensure(no * 2);
+        drh.ensure(no * 2); drl.ensure(no * 2);
+        HIP_CHECK(hipMemcpy(dxf.p, x, nx * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dwf.p, w, nw * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(drh.p, rhi.data(), no * 2, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(drl.p, rlo.data(), no * 2, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemsetAsync(dwh.p, 0, (size_t)Npad * K * 2, e->stream));
+        HIP_CHECK(hipMemsetAsync(dol.p, 0, no * 2, e->stream));
+        if (bias) { dbias.ensure((size_t)Cout * 4); HIP_CHECK(hipMemcpy(dbias.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
+        launch_f32_to_f16(ctx, dxf.as<float>(), dxh.as<half_t>(), (int64_t)nx);
+        RepackArgs r;
+        r.src = dwf.p; r.src_is_f16 = 0; r.O = Cout; r.I = Cin; r.KH = ksize; r.KW = ksize; r.in_out = 0; r.dst = dwh.as<half_t>();
+        r.dst_row0 = 0; r.Ipad = Cin; r.i0 = 0; r.Kdst = K;
+        launch_repack(ctx, r);
+        GemmArgs g;
+        g.A0 = dxh.as<half_t>(); g.lda0 = Cin; g.C0 = Cin; g.taps = taps; g.stride = 1;
+        g.Hi = Hi; g.Wi = Wi; g.Ho = Hi; g.Wo = Wi; g.M = NB * Hi * Wi; g.N = Cout; g.K = K;
+        g.W = dwh.as<half_t>(); g.Npad = Npad; g.bias = bias ? dbias.as<float>() : nullptr; g.D = doh.as<half_t>(); g.ldd = Cout;
+        g.R = drh.as<half_t>(); g.ldr = Cout;
+        if (split) { g.Rlo = drl.as<half_t>(); g.Dlo = dol.as<half_t>(); }
+        launch_gemm(ctx, g);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        HIP_CHECK(hipMemcpy(rhi.data(), doh.p, no * 2, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(rlo.data(), dol.p, no * 2, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < no; ++i) out[i] = (float)rhi[i] + (split ? (float)rlo[i] : 0.f);
+    });
+}
+
 sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const float* k, const float* v, int NB, int heads, int Sq, int Skv, int d,
                               float* out)
 {

@@ -677,7 +677,6 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
         // ================================================================ loader waves
         const int lw = wid - 8;
         const __amdgpu_buffer_rsrc_t rA0 = __builtin_amdgcn_make_buffer_rsrc((void*)p.A0, 0, OOB, RSRC_FLAGS);
-        const __amdgpu_buffer_rsrc_t rA1 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A1 ? p.A1 : p.A0), 0, OOB, RSRC_FLAGS);
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, OOB, RSRC_FLAGS);
         const int srow = lane >> 3;
         const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
@@ -692,15 +691,14 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
             hpix[j] = ok ? (unsigned)((img * p.Hi + iy) * p.Wi + ix) : 0u;
             hmask |= (ok ? 1u : 0u) << j;
         }
+        // one source tensor only: no 3x3 convolution of the models reads a channel concat through two pointers (the GroupNorm in
+        // front of it has already written the concatenated, normalised tensor); gemm_midh_supported refuses A1
+        const unsigned ld2 = (unsigned)(p.lda0 * 2);
         auto issue_halo = [&](int j, int c, int hb) {
-            const int cc = c << 6;
-            const bool second = cc >= p.C0;
-            const unsigned ld2 = (unsigned)((second ? p.lda1 : p.lda0) * 2);
-            unsigned voff = hpix[j] * ld2 + lchunk16 + (unsigned)((second ? cc - p.C0 : cc) * 2);
+            unsigned voff = hpix[j] * ld2 + lchunk16 + (unsigned)(c << 7);
             voff = (hmask >> j) & 1u ? voff : OOB;
             char* dst = smem + hb * H_BYTES + (lw + 4 * j) * 1024;
-            if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1, LDS_PTR(dst), 16, voff, 0, 0, 0);
-            else        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
         };
         const unsigned w_off = (unsigned)((n0 + lw * 40 + srow) * p.K) * 2u + lchunk16;
         const int w_step = 8 * p.K * 2;
@@ -849,7 +847,7 @@ static void launch_midl_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 // 3x3 stride-1 convolutions on whole 16 x 16 output patches: the halo kernel
 bool gemm_midh_supported(const GemmArgs& a)
 {
-    if (a.taps != 9 || a.stride != 1 || a.ups || a.coff || a.batch != 1) return false;
+    if (a.taps != 9 || a.stride != 1 || a.ups || a.coff || a.batch != 1 || a.A1 || a.C1) return false;
     if (a.Ho != a.Hi || a.Wo != a.Wi || (a.Ho & 15) || (a.Wo & 15) || a.M % (a.Ho * a.Wo)) return false;
     if (a.K % 576) return false;
     return gemm_mid_supported(a);

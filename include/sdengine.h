@@ -270,12 +270,19 @@ sde_status sde_profile_get(sde_engine* e, sde_kernel_stat* out, int capacity, in
 sde_status sde_synchronize(sde_engine* e);
 
 /* Kernel-level test hooks: run ONE contraction through the MFMA path (naive=0) or the plain path
- * (naive=1; 2 / 3 force the 256x320 / 256x160 kernels) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
+ * (naive=1; 2 / 3 force the 256x320 / 256x160 kernels, 4 / 5 the 128x160 linear / halo 3x3 kernels) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
  * upsample: 0 none, 1 nearest 2x before the conv, 2 nearest to (2*Hi-1) x (2*Wi-1) (the exported UNet's upsample to its skip
  * connection's size on odd latents). */
 sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin,
                          const float* w, const float* bias, int Cout, int ksize, int stride, int upsample,
                          float* out);
+/* As sde_test_conv (stride 1, no upsample; naive also takes 4 / 5 = the 128x160 linear kernel / the halo 3x3 kernel) with a
+ * residual added in the epilogue: residual NHWC f32 [NB,Hi,Wi,Cout].  split = 0: residual and result are plain fp16 tensors.
+ * split = 1: the residual goes in as a split-fp16 pair (hi + lo) and the result comes back as one (out = hi + lo), the form the
+ * UNet trunk uses (GemmArgs::Rlo / Dlo).  Test infrastructure; no counterpart in the reference. */
+sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin,
+                             const float* w, const float* bias, int Cout, int ksize, const float* residual, int split,
+                             float* out);
 sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const float* k, const float* v,
                               int NB, int heads, int Sq, int Skv, int d, float* out);
 

@@ -141,6 +141,43 @@ def test_conv_halo_kernel(engine, case):
     assert rel_l2(run_conv(engine, 3, x, w, b, 3, 1, 0), ref) < 2e-3      # the per-tap kernel it replaces, same operands
 
 
+RES_CASES = [
+    # kern, NB, H, W, Cin, Cout, k -- residual added in the epilogue, plain and as split-fp16 (hi + lo in, hi + lo out)
+    (5, 2, 32, 16, 128, 320, 3),     # halo kernel: the epilogue maps tile rows to patch pixels for the residual reads too
+    (5, 1, 48, 32, 192, 160, 3),
+    (5, 16, 16, 16, 640, 1280, 3),   # 128 tiles, 2-way split-K: residual applied by the reduce pass
+    (3, 1, 32, 32, 320, 320, 3),     # 256x160 per-tap kernel (loader waves)
+    (2, 1, 32, 32, 320, 320, 3),     # 256x320
+    (4, 4, 32, 32, 320, 640, 1),     # 128x160 linear kernel
+    (0, 2, 16, 16, 128, 160, 1),     # whatever the heuristic picks for a small linear
+    (1, 1, 8, 8, 64, 160, 3),        # plain kernel
+]
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("case", RES_CASES)
+def test_conv_residual_epilogue(engine, case, split):
+    from diffusers_amd import _lib
+    kern, NB, H, W, Cin, Cout, k = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31) + split)
+    x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = (rng.standard_normal((NB, H, W, Cout)) * 3).astype(np.float32)
+    out = np.empty((NB, H, W, Cout), np.float32)
+    _lib.check(_lib.lib().sde_test_conv_res(engine._h, kern, x.ctypes.data, NB, H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, k,
+                                            res.ctypes.data, split, out.ctypes.data))
+    xt = torch.from_numpy(x).half().double().permute(0, 3, 1, 2)
+    conv = F.conv2d(xt, torch.from_numpy(w).half().double(), torch.from_numpy(b).double(), stride=1, padding=k // 2).permute(0, 2, 3, 1).numpy()
+    if split:
+        # hi + lo carries ~22 bits: the residual goes in and the sum comes out essentially unrounded
+        ref = conv + res.astype(np.float64)
+        assert rel_l2(out, ref) < 2e-5, rel_l2(out, ref)
+    else:
+        ref = conv + torch.from_numpy(res).half().double().numpy()
+        assert rel_l2(out, ref) < 5e-4, rel_l2(out, ref)
+
+
 MID128_CASES = [
     # NB, H, W, Cin, Cout -- linears on the 128x160 loader-wave kernel (4-deep ring, loads three K-tiles ahead)
     (1, 16, 16, 64, 160),       # one K-tile: prologue only
