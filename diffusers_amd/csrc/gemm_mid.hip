@@ -644,13 +644,22 @@ constexpr int H_SMEM = 2 * H_BYTES + 3 * W_STG;       // 151,552 B
 // tap 8 (a tile's own issues are only known to have landed one tile later)
 constexpr int halo_cnt(int tap) { return tap == 0 || tap == 8 ? 0 : (tap <= 4 ? 2 : 1); }   // 0,2,2,2,2,1,1,1,0
 constexpr int halo_first(int tap) { return tap <= 4 ? 2 * (tap - 1) : 3 + tap; }            // -,0,2,4,6,8,9,10,-
+// UPS (fused nearest-2x upsample): the patch's halo in SOURCE pixels is 10 x 10 = 100 rows = 13 pieces, four per loader (taps 1-2)
+constexpr int halo_cnt_ups(int tap) { return tap == 1 || tap == 2 ? 2 : 0; }
+constexpr int halo_first_ups(int tap) { return 2 * (tap - 1); }
 template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 }  // namespace
 
-template <bool LO>
+// UPS: the input is the nearest-2x upsample of a (Hi/2 x Wi/2) source.  Virtual input pixel (y, x) is source pixel (y >> 1, x >> 1), so the
+// 16 x 16 patch at (Y0, X0) needs source rows Y0/2 - 1 .. Y0/2 + 8: a 10 x 10 halo, and pixel (py, px) reads tap (dy, dx) at halo row
+// ((py + dy + 1) >> 1) * 10 + ((px + dx + 1) >> 1).  Virtual rows -1 and Hi fall on source rows -1 and Hi/2: the range-checked zero fill.
+template <bool LO, bool UPS = false>
 __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
 {
+    constexpr int NP = UPS ? 4 : H_PIECES;       // halo pieces per loader
+    constexpr int HWD = UPS ? 10 : 18;           // halo width
+    constexpr int HN = HWD * HWD;                // halo rows
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -681,14 +690,14 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
         const int srow = lane >> 3;
         const unsigned lchunk16 = (unsigned)(((lane & 7) ^ srow) << 4);
         // halo piece j of this loader: rows (lw + 4j) * 8 + srow of the 18 x 18 halo (row h = hy * 18 + hx)
-        unsigned hpix[H_PIECES], hmask = 0;
+        unsigned hpix[NP], hmask = 0;
 #pragma unroll
-        for (int j = 0; j < H_PIECES; ++j) {
+        for (int j = 0; j < NP; ++j) {
             const int h = (lw + 4 * j) * 8 + srow;
-            const int hy = h / 18, hx = h - hy * 18;
-            const int iy = Y0 - 1 + hy, ix = X0 - 1 + hx;
-            const bool ok = h < 324 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            hpix[j] = ok ? (unsigned)((img * p.Hi + iy) * p.Wi + ix) : 0u;
+            const int hy = h / HWD, hx = h - hy * HWD;
+            const int iy = (UPS ? (Y0 >> 1) : Y0) - 1 + hy, ix = (UPS ? (X0 >> 1) : X0) - 1 + hx;   // source pixel (p.Hs x p.Ws; == Hi x Wi without UPS)
+            const bool ok = h < HN && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
+            hpix[j] = ok ? (unsigned)((img * p.Hs + iy) * p.Ws + ix) : 0u;
             hmask |= (ok ? 1u : 0u) << j;
         }
         // one source tensor only: no 3x3 convolution of the models reads a channel concat through two pointers (the GroupNorm in
@@ -709,7 +718,7 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
         };
         // prologue: the first chunk's halo, W of tiles 0 and 1 (a chunk is nine tiles: both exist)
 #pragma unroll
-        for (int j = 0; j < H_PIECES; ++j) issue_halo(j, c0, 0);
+        for (int j = 0; j < NP; ++j) issue_halo(j, c0, 0);
 #pragma unroll
         for (int i = 0; i < 5; ++i) issue_w(i, 0);
         st_k0 += 64;
@@ -726,9 +735,10 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
                 const bool more2 = next || tap < 7;              // tile + 2 exists
                 const int slot = (tap + 2) % 3;                  // == slot of tile - 1
                 // at most two pieces per interval: an LDS-DMA costs its issuing wave 100-150 cycles, and an interval is 20 MFMAs (320)
+                constexpr int hcnt = UPS ? halo_cnt_ups(tap) : halo_cnt(tap), hfirst = UPS ? halo_first_ups(tap) : halo_first(tap);
                 if (next) {
 #pragma unroll
-                    for (int q = 0; q < halo_cnt(tap); ++q) issue_halo(halo_first(tap) + q, c + 1, hb ^ 1);
+                    for (int q = 0; q < hcnt; ++q) issue_halo(hfirst + q, c + 1, hb ^ 1);
                 }
                 BAR();
                 if (more2) { issue_w(0, slot); issue_w(1, slot); }
@@ -737,7 +747,7 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
                 BAR();
                 if (more2) { issue_w(4, slot); st_k0 += 64; }
                 // in flight afterwards: this tile's own issues only (the halo pieces above, W of tile + 2)
-                if (more2) { if (next) wait_vmcnt<5 + halo_cnt(tap)>(); else wait_vmcnt<5>(); }
+                if (more2) { if (next) wait_vmcnt<5 + hcnt>(); else wait_vmcnt<5>(); }
                 else wait_vmcnt<0>();
                 BAR();
             });
@@ -752,7 +762,8 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
     const int fr = lane & 15, fg = lane >> 4;
     const int swz0 = ((fg) ^ (fr & 7)) << 4, swz1 = ((4 + fg) ^ (fr & 7)) << 4;
     const int b_rd0 = (wc * WN + fr) * 128 + swz0, b_rd1 = (wc * WN + fr) * 128 + swz1;
-    const int hrow0 = wr * 4 * 18 + fr;          // halo row of this lane's pixel in patch row wr*4, tap (0,0)
+    // halo row of this lane's pixel in patch row wr*4, tap (0,0); UPS: the lane's pixel column alone (rows and columns are halved per tap)
+    const int hrow0 = UPS ? fr : wr * 4 * 18 + fr;
     floatx4 acc[NT][MT];
 #pragma unroll
     for (int a = 0; a < NT; ++a)
@@ -764,7 +775,7 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
 #define LOAD_FRAGS_H(bo, kc, tapoff)                                                                  \
     _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(curw + (bo) + nt * 2048);  \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                \
-        const int h_ = hr + mt * 18 + (tapoff);                                                       \
+        const int h_ = UPS ? ((wr * 4 + mt + tap / 3 + 1) >> 1) * 10 + ((hr + tap % 3 + 1) >> 1) : hr + mt * 18 + (tapoff);   \
         af[mt] = *(const half8*)(curh + (h_ << 7) + ((((kc) ^ h_) & 7) << 4));                         \
     }
 #define MFMA_ALL()                                                                                    \
@@ -847,7 +858,10 @@ static void launch_midl_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
 // 3x3 stride-1 convolutions on whole 16 x 16 output patches: the halo kernel
 bool gemm_midh_supported(const GemmArgs& a)
 {
-    if (a.taps != 9 || a.stride != 1 || a.ups || a.coff || a.batch != 1 || a.A1 || a.C1) return false;
+    if (a.taps != 9 || a.stride != 1 || a.coff || a.batch != 1 || a.A1 || a.C1) return false;
+    static const int ups_env = getenv("SDE_HALOUPS") ? atoi(getenv("SDE_HALOUPS")) : 1;   // tuning hook: 0 = upsampling convs stay on the per-tap kernels
+    if (a.ups && !ups_env) return false;
+    // a.ups: Hi x Wi is the virtual (upsampled) size; the cropped variant (2H - 1) is odd and fails the patch rule
     if (a.Ho != a.Hi || a.Wo != a.Wi || (a.Ho & 15) || (a.Wo & 15) || a.M % (a.Ho * a.Wo)) return false;
     if (a.K % 576) return false;
     return gemm_mid_supported(a);
@@ -859,15 +873,13 @@ void launch_gemm_midh(const LaunchCtx& ctx, GemmDev& p)
     p.nbn = p.Npad / BN;
     SDE_REQUIRE(p.splitk >= 1 && p.splitk <= p.K / 576, SDE_ERR_INVALID_ARGUMENT, "launch_gemm_midh: more split-K ways than 64-channel chunks");
     dim3 grid(p.nbm * p.nbn, p.splitk, 1);
-    if (p.Rlo || p.Dlo) {
-        auto kern = gemm_midh_kernel<true>;
+    auto go = [&](auto kern) {
         allow_dynamic_lds((const void*)kern, H_SMEM);
         hipLaunchKernelGGL(kern, grid, dim3(768), H_SMEM, ctx.stream, p);
-    } else {
-        auto kern = gemm_midh_kernel<false>;
-        allow_dynamic_lds((const void*)kern, H_SMEM);
-        hipLaunchKernelGGL(kern, grid, dim3(768), H_SMEM, ctx.stream, p);
-    }
+    };
+    const bool lo = p.Rlo || p.Dlo;
+    if (p.ups) { if (lo) go(gemm_midh_kernel<true, true>); else go(gemm_midh_kernel<false, true>); }
+    else       { if (lo) go(gemm_midh_kernel<true, false>); else go(gemm_midh_kernel<false, false>); }
 }
 
 // 128x160 tiles (linears only): 4 compute + 4 loader waves, 4-deep ring

@@ -114,31 +114,39 @@ def test_conv_big_tile_kernel(engine, case):
 
 
 HALO_CASES = [
-    # NB, H, W, Cin, Cout -- 3x3 stride-1 convs on the halo kernel (16 x 16 output patches, input staged once per 64-channel chunk)
-    (1, 16, 16, 64, 160),       # one patch, one chunk (prologue only: no second halo)
-    (2, 32, 16, 128, 320),      # two images x two patches, two chunks (the halo buffers swap once), two column tiles
-    (1, 48, 32, 192, 160),      # 3 x 2 patches: interior edges read the neighbour patch's pixels, outer edges the zero fill
-    (1, 32, 32, 320, 320),      # five chunks
-    (3, 16, 16, 640, 640),      # ten chunks, 4 column tiles
-    (16, 16, 16, 1280, 1280),   # the 16x16 UNet level at batch 16: 128 tiles, 2-way split-K at a chunk boundary
-    (4, 16, 16, 1280, 160),     # few tiles, 20 chunks: 8-way split (2-3 chunks per split)
-    (2, 64, 64, 64, 160),       # 32 patches, borders on every side
+    # NB, H, W, Cin, Cout, ups -- 3x3 stride-1 convs on the halo kernel (16 x 16 output patches, input staged once per 64-channel chunk)
+    (1, 16, 16, 64, 160, 0),       # one patch, one chunk (prologue only: no second halo)
+    (2, 32, 16, 128, 320, 0),      # two images x two patches, two chunks (the halo buffers swap once), two column tiles
+    (1, 48, 32, 192, 160, 0),      # 3 x 2 patches: interior edges read the neighbour patch's pixels, outer edges the zero fill
+    (1, 32, 32, 320, 320, 0),      # five chunks
+    (3, 16, 16, 640, 640, 0),      # ten chunks, 4 column tiles
+    (16, 16, 16, 1280, 1280, 0),   # the 16x16 UNet level at batch 16: 128 tiles, 2-way split-K at a chunk boundary
+    (4, 16, 16, 1280, 160, 0),     # few tiles, 20 chunks: 8-way split (2-3 chunks per split)
+    (2, 64, 64, 64, 160, 0),       # 32 patches, borders on every side
+    # fused nearest-2x upsample (H, W = source size): a 10 x 10 source halo per patch
+    (1, 8, 8, 64, 160, 1),         # one patch
+    (2, 16, 8, 128, 320, 1),       # 2 x 1 patches per image, two chunks
+    (1, 24, 16, 192, 160, 1),      # 3 x 2 patches, three chunks
+    (16, 8, 8, 1280, 1280, 1),     # the 8x8 -> 16x16 upsampler at batch 16: split-K
+    (2, 32, 32, 640, 640, 1),      # 32x32 -> 64x64, ten chunks
 ]
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
 def test_conv_halo_kernel(engine, case):
-    NB, H, W, Cin, Cout = case
+    NB, H, W, Cin, Cout, ups = case
     rng = np.random.default_rng(hash(case) % (2 ** 31))
     x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
     w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)
     b = rng.standard_normal(Cout).astype(np.float32)
-    got = run_conv(engine, 5, x, w, b, 3, 1, 0)
+    got = run_conv(engine, 5, x, w, b, 3, 1, ups)
     xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
+    if ups:
+        xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
     ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=1, padding=1).permute(0, 2, 3, 1).numpy()
     assert got.shape == ref.shape
     assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
-    assert rel_l2(run_conv(engine, 3, x, w, b, 3, 1, 0), ref) < 2e-3      # the per-tap kernel it replaces, same operands
+    assert rel_l2(run_conv(engine, 3, x, w, b, 3, 1, ups), ref) < 2e-3      # the per-tap kernel it replaces, same operands
 
 
 RES_CASES = [
