@@ -103,13 +103,14 @@ def cpu_baseline(model_dir, seconds_budget=60.0):
 # plain and the GEGLU linears both run gemm_big_kernel<false, false, 5, 0, ..>): the roofline object is computed PER SYMBOL, so that it
 # can be checked line by line against `rocprofv3 --kernel-trace --stats` (profiles/*kernel_stats*.csv).  Placeholders stand for
 # template arguments that select a variant of the same kernel and are summed over: UPS (fused 2x upsample in the loader), LO (the
-# split-fp16 epilogue instance: rows `..., false>` and `..., true>` of the CSV), BM / BN (tile of the 4-wave kernel), ONES / FOLD.
+# split-fp16 epilogue instance: rows `..., false>` and `..., true>` of the CSV), BM / BN (tile of the 4-wave kernel), NT (16-column tiles
+# per wave of the halo kernel: 5 = 160-column, 4 = 128-column block tiles), ONES / FOLD.
 ROCPROF_SYMBOL = {
     "conv3x3_mfma_256x320": "gemm_big_kernel<true, UPS, 5, 0, LO>", "conv3x3_mfma_256x256": "gemm_big_kernel<true, UPS, 4, 0, LO>",
     "gemm_mfma_256x320": "gemm_big_kernel<false, false, 5, 0, LO>", "gemm_geglu_mfma_256x320": "gemm_big_kernel<false, false, 5, 0, LO>",
     "gemm_mfma_256x256": "gemm_big_kernel<false, false, 4, 0, LO>",
     "conv3x3_mfma_256x160": "gemm_midl_kernel<true, UPS, LO, 256>", "gemm_mfma_256x160": "gemm_mid_kernel<false, false, 0, LO>",
-    "gemm_mfma_ldw128": "gemm_midl_kernel<false, false, LO, 128>", "conv3x3_mfma_halo": "gemm_midh_kernel<LO>",
+    "gemm_mfma_ldw128": "gemm_midl_kernel<false, false, LO, 128>", "conv3x3_mfma_halo": "gemm_midh_kernel<LO, UPS, NT>",
     "conv3x3_mfma": "gemm_mfma_kernel<BM, BN, true>", "gemm_mfma": "gemm_mfma_kernel<BM, BN, false>",
     "splitk_reduce": "splitk_reduce_kernel",
 }

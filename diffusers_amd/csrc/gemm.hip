@@ -381,6 +381,19 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     GemmDev p = to_dev(ctx, a);
     const double flops = 2.0 * a.M * (double)a.N * a.K * a.batch;
     const double bytes = ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N * (1 + (a.R ? 1 : 0) + (a.Rlo ? 1 : 0) + (a.Dlo ? 1 : 0))) * 2.0 * a.batch;
+    // 3x3 stride-1 convs whose width is a multiple of 128 but not of 160 (the VAE decoder: 128 / 256 / 512 channels): the halo kernel on
+    // 256x128 tiles.  Measured at batch 8 against the 256x256 / 4-wave kernels they ran on (us): 512^2 128->128 1,150 -> 700;
+    // 256^2 256->256 621 -> 530; 128^2 512->512 575 -> 483, with fused upsample 2,444 -> 1,870; 64^2 512->512 146 -> 124.
+    static const int halo128_env = getenv("SDE_HALO128") ? atoi(getenv("SDE_HALO128")) : 1;   // tuning hook
+    if (!ctx.force_naive && !ctx.force_big && !ctx.force_mid && a.taps == 9 && a.Npad % 160 != 0 && !a.Rlo && !a.Dlo &&
+        (halo128_env || ctx.force_midh) && gemm_midh_supported(a) && (ctx.force_midh || cdiv(a.M, 256) * (a.Npad / 128) >= 192)) {
+        {
+            ProfScope ps(ctx, prof_name("conv3x3_mfma_halo", a, "Q"), flops, bytes);
+            launch_gemm_midh(ctx, p);
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     static const int big_env = getenv("SDE_BIG") ? atoi(getenv("SDE_BIG")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
     if (!ctx.force_naive && big_env && !ctx.force_mid && !ctx.force_midh && !ctx.force_mid128 && gemm_big_supported(a)) {
         // 8-wave 256x320 tiles, one block per CU: worth it once the grid (with split-K on long K) covers most of the chip
@@ -394,7 +407,7 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         // long-K 3x3 convs the halo kernel takes (64x64 level, N = 320 as two 160-column tiles): 193 us against 205 at K = 5760; at
         // K = 2880 the two tie (111.5 / 111.0) and the 256x320 tile keeps them
         static const int halo64_env = getenv("SDE_HALO64") ? atoi(getenv("SDE_HALO64")) : 1;   // tuning hook
-        const bool to_halo = halo64_env && !ctx.force_big && big_env != 2 && a.taps == 9 && a.K >= 5760 && sk == 1 && gemm_midh_supported(a) &&
+        const bool to_halo = halo64_env && !ctx.force_big && big_env != 2 && a.taps == 9 && a.K >= 5760 && sk == 1 && a.Npad % 160 == 0 && gemm_midh_supported(a) &&
                              cdiv(a.M, 256) * (a.Npad / 160) >= 192;
         if (!to_halo && (big_env == 2 || ctx.force_big || tiles * sk >= 192 || a.epi == EPI_GEGLU_PAIR)) {
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;

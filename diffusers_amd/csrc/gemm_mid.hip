@@ -49,10 +49,12 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 #endif
 // LO: split-fp16 residual / result (hi + lo pairs); its own instance so the plain epilogue keeps its register budget (gemm_big.hip)
 // PATCH: the tile's 256 rows are a 16 x 16 patch of output pixels (halo kernel below): tile row r is pixel m0 + (r >> 4) * Wo + (r & 15)
-template <bool LO, int SLICE = SMEM_BYTES / 8, bool PATCH = false>
-__device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT][MT], int m0, int n0, int ks, int z,
+// NT_: 16-column tiles per wave (5: 160-column block tile; 4: 128-column, the halo kernel on VAE widths)
+template <bool LO, int SLICE = SMEM_BYTES / 8, bool PATCH = false, int NT_ = 5>
+__device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT_][MT], int m0, int n0, int ks, int z,
                                              int wid, int wr, int wc, int lane, int fr, int fg)
 {
+    constexpr int NT = NT_, WN = NT_ * 16;   // shadow the file-scope constants
     // ---- epilogue: acc[nt][mt][r] <-> n = n0 + wc*80 + nt*16 + 4*fg + r ; m = m0 + wr*64 + mt*16 + fr
     const long long zD = z * p.sD, zR = z * p.sR;
     auto rowm = [&](int r) { return PATCH ? m0 + (r >> 4) * p.Wo + (r & 15) : m0 + r; };
@@ -654,9 +656,13 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { st
 // UPS: the input is the nearest-2x upsample of a (Hi/2 x Wi/2) source.  Virtual input pixel (y, x) is source pixel (y >> 1, x >> 1), so the
 // 16 x 16 patch at (Y0, X0) needs source rows Y0/2 - 1 .. Y0/2 + 8: a 10 x 10 halo, and pixel (py, px) reads tap (dy, dx) at halo row
 // ((py + dy + 1) >> 1) * 10 + ((px + dx + 1) >> 1).  Virtual rows -1 and Hi fall on source rows -1 and Hi/2: the range-checked zero fill.
-template <bool LO, bool UPS = false>
+// NT_ = 4: 256 x 128 block tile (wave tile 64 x 64) for widths that are multiples of 128 but not of 160 (the VAE decoder's 128-channel
+// convolutions at 512 x 512 ran on the 4-wave 128x128 kernel at 0.5 PFLOP/s: 32 KB through L2 -> LDS per 2.1 MFLOP K-tile).
+template <bool LO, bool UPS = false, int NT_ = 5>
 __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
 {
+    constexpr int NT = NT_, WN = NT_ * 16, BN = 2 * WN, W_STG = BN * 128;   // shadow the file-scope constants
+    constexpr int NWP = BN / 32;                 // W pieces per loader and K-tile (5 or 4)
     constexpr int NP = UPS ? 4 : H_PIECES;       // halo pieces per loader
     constexpr int HWD = UPS ? 10 : 18;           // halo width
     constexpr int HN = HWD * HWD;                // halo rows
@@ -709,23 +715,23 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
             char* dst = smem + hb * H_BYTES + (lw + 4 * j) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0, LDS_PTR(dst), 16, voff, 0, 0, 0);
         };
-        const unsigned w_off = (unsigned)((n0 + lw * 40 + srow) * p.K) * 2u + lchunk16;
+        const unsigned w_off = (unsigned)((n0 + lw * (NWP * 8) + srow) * p.K) * 2u + lchunk16;
         const int w_step = 8 * p.K * 2;
         int st_k0 = c0 * 576;
         auto issue_w = [&](int i, int slot) {
-            char* dst = wbase + slot * W_STG + (lw * 5 + i) * 1024;
+            char* dst = wbase + slot * W_STG + (lw * NWP + i) * 1024;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, w_off, i * w_step + st_k0 * 2, 0, 0);
         };
         // prologue: the first chunk's halo, W of tiles 0 and 1 (a chunk is nine tiles: both exist)
 #pragma unroll
         for (int j = 0; j < NP; ++j) issue_halo(j, c0, 0);
 #pragma unroll
-        for (int i = 0; i < 5; ++i) issue_w(i, 0);
+        for (int i = 0; i < NWP; ++i) issue_w(i, 0);
         st_k0 += 64;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) issue_w(i, 1);
+        for (int i = 0; i < NWP; ++i) issue_w(i, 1);
         st_k0 += 64;
-        wait_vmcnt<5>();
+        wait_vmcnt<NWP>();
         __builtin_amdgcn_s_barrier();
         int hb = 0;
         for (int c = c0; c < c1; ++c) {
@@ -745,9 +751,9 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
                 BAR();
                 if (more2) { issue_w(2, slot); issue_w(3, slot); }
                 BAR();
-                if (more2) { issue_w(4, slot); st_k0 += 64; }
+                if (more2) { if (NWP == 5) issue_w(4, slot); st_k0 += 64; }
                 // in flight afterwards: this tile's own issues only (the halo pieces above, W of tile + 2)
-                if (more2) { if (next) wait_vmcnt<5 + hcnt>(); else wait_vmcnt<5>(); }
+                if (more2) { if (next) wait_vmcnt<NWP + hcnt>(); else wait_vmcnt<NWP>(); }
                 else wait_vmcnt<0>();
                 BAR();
             });
@@ -812,20 +818,21 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
 #undef BAR
 #undef FENCE
     const int pbase = (img * p.Ho + Y0) * p.Wo + X0;
-    mid_epilogue<LO, H_SMEM / 8, true>(p, smem, acc, pbase, n0, ks, 0, wid, wr, wc, lane, fr, fg);
+    mid_epilogue<LO, H_SMEM / 8, true, NT_>(p, smem, acc, pbase, n0, ks, 0, wid, wr, wc, lane, fr, fg);
 }
 
 // ------------------------------------------------------------------------------------------ host side
 bool gemm_big_supported(const GemmArgs& a);   // gemm_big.hip: shared operand rules
 
-bool gemm_mid_supported(const GemmArgs& a)
+static bool mid_operands_ok(const GemmArgs& a, int bn)
 {
-    if (a.epi != EPI_STD || a.Npad % BN || (a.N & 7)) return false;
+    if (a.epi != EPI_STD || a.Npad % bn || (a.N & 7)) return false;
     if ((a.Rlo || a.Dlo) && ((a.ldd & 7) || (a.R && (a.ldr & 7)))) return false;   // the split-fp16 epilogue has 16-byte paths only
     GemmArgs c = a;
     c.Npad = 320 * ((a.Npad + 319) / 320);   // reuse the operand / offset-range rules, not the tile-width rule
     return gemm_big_supported(c);
 }
+bool gemm_mid_supported(const GemmArgs& a) { return mid_operands_ok(a, BN); }
 
 template <bool CONV, bool UPS, int VAR = 0>
 static void launch_mid_t(const LaunchCtx& ctx, const GemmDev& p, dim3 grid)
@@ -864,13 +871,14 @@ bool gemm_midh_supported(const GemmArgs& a)
     // a.ups: Hi x Wi is the virtual (upsampled) size; the cropped variant (2H - 1) is odd and fails the patch rule
     if (a.Ho != a.Hi || a.Wo != a.Wi || (a.Ho & 15) || (a.Wo & 15) || a.M % (a.Ho * a.Wo)) return false;
     if (a.K % 576) return false;
-    return gemm_mid_supported(a);
+    return mid_operands_ok(a, a.Npad % BN == 0 ? BN : 128);   // 160-column tiles, else 128-column ones
 }
 
 void launch_gemm_midh(const LaunchCtx& ctx, GemmDev& p)
 {
+    const bool n160 = p.Npad % BN == 0;
     p.nbm = p.M / BM;
-    p.nbn = p.Npad / BN;
+    p.nbn = p.Npad / (n160 ? BN : 128);
     SDE_REQUIRE(p.splitk >= 1 && p.splitk <= p.K / 576, SDE_ERR_INVALID_ARGUMENT, "launch_gemm_midh: more split-K ways than 64-channel chunks");
     dim3 grid(p.nbm * p.nbn, p.splitk, 1);
     auto go = [&](auto kern) {
@@ -878,6 +886,11 @@ void launch_gemm_midh(const LaunchCtx& ctx, GemmDev& p)
         hipLaunchKernelGGL(kern, grid, dim3(768), H_SMEM, ctx.stream, p);
     };
     const bool lo = p.Rlo || p.Dlo;
+    if (!n160) {   // VAE widths: no split-fp16 tensors there
+        SDE_REQUIRE(!lo, SDE_ERR_INVALID_ARGUMENT, "launch_gemm_midh: split-fp16 epilogue needs a 160-column tiling");
+        if (p.ups) go(gemm_midh_kernel<false, true, 4>); else go(gemm_midh_kernel<false, false, 4>);
+        return;
+    }
     if (p.ups) { if (lo) go(gemm_midh_kernel<true, true>); else go(gemm_midh_kernel<false, true>); }
     else       { if (lo) go(gemm_midh_kernel<true, false>); else go(gemm_midh_kernel<false, false>); }
 }

@@ -129,6 +129,12 @@ HALO_CASES = [
     (1, 24, 16, 192, 160, 1),      # 3 x 2 patches, three chunks
     (16, 8, 8, 1280, 1280, 1),     # the 8x8 -> 16x16 upsampler at batch 16: split-K
     (2, 32, 32, 640, 640, 1),      # 32x32 -> 64x64, ten chunks
+    # 256 x 128 tiles (widths that are multiples of 128 only: the VAE decoder)
+    (1, 16, 16, 64, 128, 0),
+    (2, 32, 48, 128, 128, 0),      # two chunks, 6 patches per image
+    (1, 32, 32, 256, 256, 0),      # two column tiles
+    (1, 16, 16, 512, 512, 1),      # fused upsample, four column tiles, eight chunks
+    (1, 64, 64, 128, 384, 0),      # three column tiles
 ]
 
 

@@ -15,6 +15,10 @@ CONVS = [  # H, Cin, Cout, k, stride, ups
     (16, 1280, 1280, 1, 1, 0), (16, 2560, 1280, 1, 1, 0), (16, 5120, 1280, 1, 1, 0), (64, 320, 2560, 1, 1, 0),
     (64, 64, 320, 1, 1, 0), (64, 64, 2560, 1, 1, 0),   # one K-tile: prologue + epilogue cost of the 256x320 kernel (1 and 8 rounds of blocks)
 ]
+VAE = [  # NB=8 shapes of the SD VAE decoder (MB_ONLY=vae NB=8): H, Cin, Cout, k, stride, ups
+    (64, 512, 512, 3, 1, 0), (128, 512, 512, 3, 1, 0), (64, 512, 512, 3, 1, 1), (256, 512, 256, 3, 1, 0), (256, 256, 256, 3, 1, 0),
+    (128, 512, 512, 3, 1, 1), (512, 256, 128, 3, 1, 0), (512, 128, 128, 3, 1, 0), (256, 256, 256, 3, 1, 1),
+]
 ATTN = [(8, 4096, 4096, 40), (8, 1024, 1024, 80), (8, 256, 256, 160), (8, 4096, 77, 40), (8, 1024, 77, 80)]
 
 
@@ -29,7 +33,7 @@ def main():
     rng = np.random.default_rng(0)
     reps = 4
     only = os.environ.get("MB_ONLY", "")
-    convs = [c for c in CONVS if not only or (only == "small" and NB * c[0] * c[0] <= 4096) or (only == "big" and NB * c[0] * c[0] > 4096)
+    convs = VAE if only == "vae" else [c for c in CONVS if not only or (only == "small" and NB * c[0] * c[0] <= 4096) or (only == "big" and NB * c[0] * c[0] > 4096)
              or (only == "c64" and c[0] == 64 and c[3] == 3 and c[4] == 1) or (only == "k64" and c[1] == 64) or (only == "wide" and c[3] == 1 and c[2] >= 960) or (only == "lin16" and c[0] == 16 and c[3] == 1) or (only == "lin64" and c[0] == 64 and c[3] == 1 and c[1] >= 320) or (only == "c32" and c[0] == 32 and c[3] == 3 and c[5] == 0)]
     for (H, Cin, Cout, k, stride, ups) in convs:
         x = rng.standard_normal((NB, H, H, Cin), dtype=np.float32)

@@ -58,7 +58,7 @@ def symbol_key(name: str) -> str:
     if base == "gemm_mid_kernel" and len(t) >= 3:
         return f"gemm_mid_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, LO>"
     if base == "gemm_midh_kernel":
-        return "gemm_midh_kernel<LO>"
+        return "gemm_midh_kernel<LO, UPS, NT>"
     if base == "gemm_mfma_kernel" and len(t) >= 3:
         return f"gemm_mfma_kernel<BM, BN, {t[2]}>"
     if base == "attn_mfma_kernel" and len(t) >= 2:
