@@ -50,7 +50,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // LO: split-fp16 residual / result (hi + lo pairs); its own instance so the plain epilogue keeps its register budget (gemm_big.hip)
 // PATCH: the tile's 256 rows are a 16 x 16 patch of output pixels (halo kernel below): tile row r is pixel m0 + (r >> 4) * Wo + (r & 15)
 // NT_: 16-column tiles per wave (5: 160-column block tile; 4: 128-column, the halo kernel on VAE widths)
-template <bool LO, int SLICE = SMEM_BYTES / 8, bool PATCH = false, int NT_ = 5>
+template <bool LO, int SLICE = SMEM_BYTES / 8, bool PATCH = false, int NT_ = 5, int RG_ = MID_RG(LO)>
 __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, floatx4 (&acc)[NT_][MT], int m0, int n0, int ks, int z,
                                              int wid, int wr, int wc, int lane, int fr, int fg)
 {
@@ -77,14 +77,19 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
     char* const wlds = smem + wid * SLICE;
     const bool vec_ok = (p.ldd & 7) == 0;
     constexpr int PITCH = WN * 4 + 32, CH = WN / 8;
-    constexpr int RG = MID_RG(LO);          // 16-row groups per step (gemm_big.hip: the split-fp16 instance takes one)
+    constexpr int RG = RG_;                 // 16-row groups per step (gemm_big.hip: the split-fp16 instance takes one)
     constexpr int NCH = RG * 16 * CH, NI = (NCH + 63) / 64;
-    float bv[NT][4];
+    // 16-row steps (RG_ == 1): the bias is re-read per step (L1 hits) instead of living in 20 registers next to the residual sets: the
+    // 12-wave kernels have 168 VGPRs and every spilled dword in this epilogue is a scratch round trip in the tile's latency chain
+    constexpr bool BIL = RG_ == 1;   // bias in the loop: the split-fp16 instances and the 12-wave kernels
+    float bv[BIL ? 1 : NT][4];
+    if constexpr (!BIL) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + wc * WN + nt * 16 + 4 * fg;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = n0 + wc * WN + nt * 16 + 4 * fg;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
+            for (int r = 0; r < 4; ++r) bv[nt][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
+        }
     }
     const half_t* R = p.R ? p.R + zR : nullptr;
     const half_t* Rlo = (LO && p.R && p.Rlo) ? p.Rlo + zR : nullptr;   // split-fp16 residual / result (kernels.h)
@@ -112,8 +117,13 @@ __device__ __forceinline__ void mid_epilogue(const GemmDev& p, char* smem, float
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 floatx4 o;
+                if constexpr (BIL) {
+                    const int n = n0 + wc * WN + nt * 16 + 4 * fg;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[nt][r];
+                    for (int r = 0; r < 4; ++r) bv[0][r] = (p.bias && n < p.N) ? p.bias[n + r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[nt][mt][r] * p.alpha + bv[BIL ? 0 : nt][r];
                 *(floatx4*)(wlds + (mq * 16 + fr) * PITCH + (nt * 16 + 4 * fg) * 4) = o;
             }
         }
@@ -658,6 +668,9 @@ template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { st
 // ((py + dy + 1) >> 1) * 10 + ((px + dx + 1) >> 1).  Virtual rows -1 and Hi fall on source rows -1 and Hi/2: the range-checked zero fill.
 // NT_ = 4: 256 x 128 block tile (wave tile 64 x 64) for widths that are multiples of 128 but not of 160 (the VAE decoder's 128-channel
 // convolutions at 512 x 512 ran on the 4-wave 128x128 kernel at 0.5 PFLOP/s: 32 KB through L2 -> LDS per 2.1 MFLOP K-tile).
+#ifndef MIDH_RG
+#define MIDH_RG 1
+#endif
 template <bool LO, bool UPS = false, int NT_ = 5>
 __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
 {
@@ -818,7 +831,8 @@ __global__ __launch_bounds__(768) void gemm_midh_kernel(GemmDev p)
 #undef BAR
 #undef FENCE
     const int pbase = (img * p.Ho + Y0) * p.Wo + X0;
-    mid_epilogue<LO, H_SMEM / 8, true, NT_>(p, smem, acc, pbase, n0, ks, 0, wid, wr, wc, lane, fr, fg);
+    // 16-row epilogue steps on the 160-column tiles (32-row steps spill 35 registers here: 3 us per launch); the 128-column tiles have room
+    mid_epilogue<LO, H_SMEM / 8, true, NT_, (NT_ == 5 ? MIDH_RG : 2)>(p, smem, acc, pbase, n0, ks, 0, wid, wr, wc, lane, fr, fg);
 }
 
 // ------------------------------------------------------------------------------------------ host side
