@@ -404,10 +404,10 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
             if (ctx.splitk_force > 0) sk = std::max(1, std::min(ctx.splitk_force, nk / 4));
             while (sk > 1 && (size_t)sk * a.M * a.Npad * sizeof(float) > std::min(ctx.splitk_ws_bytes, (size_t)48 << 20)) --sk;   // slab traffic must stay small next to the GEMM
         }
-        // long-K 3x3 convs the halo kernel takes (64x64 level, N = 320 as two 160-column tiles): 193 us against 205 at K = 5760; at
-        // K = 2880 the two tie (111.5 / 111.0) and the 256x320 tile keeps them
+        // 3x3 convs the halo kernel takes (64x64 level, N = 320 as two 160-column tiles): 185 us against 204 at K = 5760, 102.6 against
+        // 110.6 at K = 2880 (a tie, 111.5 / 111.0, until the halo kernel's epilogue stopped spilling)
         static const int halo64_env = getenv("SDE_HALO64") ? atoi(getenv("SDE_HALO64")) : 1;   // tuning hook
-        const bool to_halo = halo64_env && !ctx.force_big && big_env != 2 && a.taps == 9 && a.K >= 5760 && sk == 1 && a.Npad % 160 == 0 && gemm_midh_supported(a) &&
+        const bool to_halo = halo64_env && !ctx.force_big && big_env != 2 && a.taps == 9 && a.K >= 2880 && sk == 1 && a.Npad % 160 == 0 && gemm_midh_supported(a) &&
                              cdiv(a.M, 256) * (a.Npad / 160) >= 192;
         if (!to_halo && (big_env == 2 || ctx.force_big || tiles * sk >= 192 || a.epi == EPI_GEGLU_PAIR)) {
             p.splitk = sk; p.ws = sk > 1 ? ctx.splitk_ws : nullptr;
