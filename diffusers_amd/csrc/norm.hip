@@ -104,9 +104,10 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const half_t* X0, const h
 
 // X0lo / X1lo: low parts of split-fp16 inputs (kernels.h), or null.  The statistics pass reads the high parts only (a 2^-11
 // relative perturbation per element moves a group's mean / variance by ~2^-11 / sqrt(count)); the normalised value uses hi + lo.
+template <bool LO, bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const half_t* X1, const half_t* X0lo, const half_t* X1lo, int C0, int C1, int HW, int rows_per_block,
                                                        const float* part, int nchunks, int groups, float eps, const float* gamma,
-                                                       const float* beta, int silu, half_t* Y)
+                                                       const float* beta, half_t* Y)
 {
     extern __shared__ float sh[];   // ab[C][2] | mean[groups] | rstd[groups]
     const int C = C0 + C1, CX = C >> 3;
@@ -142,40 +143,59 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const half_t* X0, const h
     const int r0 = blockIdx.x * rows_per_block, r1 = min(HW, r0 + rows_per_block);
     const long long base_row = (long long)nb * HW;
     const int total = (r1 - r0) * CX;
-    // 4 octets per trip: all loads first, so 4 x 16 B per thread are in flight
-    for (int i0 = tid; i0 < total; i0 += 4 * blockDim.x) {
-        half8 v[4], vl[4];
-        int cc[4]; long long rw[4];
+    // 4 octets per trip and two trips in flight: the loads of trip t+1 are issued before trip t is normalised and stored, so a
+    // thread's HBM round trips overlap its arithmetic (cvt / fma / exp / rcp: ~12 issue slots per element with SiLU) and its stores
+    constexpr int S = 4 * 256;
+    struct Trip { half8 v[4], vl[LO ? 4 : 1]; int cc[4]; long long rw[4]; };
+    auto load = [&](int i0, Trip& t) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + u * (int)blockDim.x, total - 1);
+            const int i = min(i0 + u * 256, total - 1);
             const int rr = i / CX;
-            cc[u] = (i - rr * CX) * 8;
-            rw[u] = base_row + r0 + rr;
-            const bool first = cc[u] < C0;
-            const long long off = first ? rw[u] * C0 + cc[u] : rw[u] * C1 + (cc[u] - C0);
-            v[u] = *(const half8*)((first ? X0 : X1) + off);
-            const half_t* lo = first ? X0lo : X1lo;
-            if (lo) vl[u] = *(const half8*)(lo + off);
-            else
+            t.cc[u] = (i - rr * CX) * 8;
+            t.rw[u] = base_row + r0 + rr;
+            const bool first = t.cc[u] < C0;
+            const long long off = first ? t.rw[u] * C0 + t.cc[u] : t.rw[u] * C1 + (t.cc[u] - C0);
+            t.v[u] = *(const half8*)((first ? X0 : X1) + off);
+            if constexpr (LO) {
+                const half_t* lo = first ? X0lo : X1lo;
+                if (lo) t.vl[u] = *(const half8*)(lo + off);
+                else
 #pragma unroll
-                for (int j = 0; j < 8; ++j) vl[u][j] = (half_t)0.f;
+                    for (int j = 0; j < 8; ++j) t.vl[u][j] = (half_t)0.f;
+            }
         }
+    };
+    auto emit = [&](int i0, const Trip& t) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i0 + u * (int)blockDim.x < total) {
-                const float4* abp = (const float4*)(ab + 2 * cc[u]);
+            if (i0 + u * 256 < total) {
+                const float4* abp = (const float4*)(ab + 2 * t.cc[u]);
                 half8 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 t = abp[j];
-                    float y0 = ((float)v[u][2 * j] + (float)vl[u][2 * j]) * t.x + t.y, y1 = ((float)v[u][2 * j + 1] + (float)vl[u][2 * j + 1]) * t.z + t.w;
-                    if (silu) { y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0)); y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1)); }   // v_rcp_f32 (1 ulp), not the 11-instruction IEEE division
+                    const float4 q = abp[j];
+                    float x0 = (float)t.v[u][2 * j], x1 = (float)t.v[u][2 * j + 1];
+                    if constexpr (LO) { x0 += (float)t.vl[u][2 * j]; x1 += (float)t.vl[u][2 * j + 1]; }
+                    float y0 = x0 * q.x + q.y, y1 = x1 * q.z + q.w;
+                    if constexpr (SILU) { y0 = y0 * __builtin_amdgcn_rcpf(1.0f + __expf(-y0)); y1 = y1 * __builtin_amdgcn_rcpf(1.0f + __expf(-y1)); }   // v_rcp_f32 (1 ulp), not the 11-instruction IEEE division
                     o[2 * j] = (half_t)y0; o[2 * j + 1] = (half_t)y1;
                 }
-                *(half8*)(Y + rw[u] * C + cc[u]) = o;
+                *(half8*)(Y + t.rw[u] * C + t.cc[u]) = o;
             }
         }
+    };
+    Trip ta, tb;
+    int i0 = tid;
+    if (i0 < total) load(i0, ta);
+    while (i0 < total) {
+        if (i0 + S < total) load(i0 + S, tb);
+        emit(i0, ta);
+        i0 += S;
+        if (i0 >= total) break;
+        if (i0 + S < total) load(i0 + S, ta);
+        emit(i0, tb);
+        i0 += S;
     }
 }
 
@@ -315,8 +335,12 @@ void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
         int bpi = std::max(1, std::min(cdiv(1024, a.NB), cdiv(a.HW, 16)));
         const int rpb = cdiv(a.HW, bpi);
         bpi = cdiv(a.HW, rpb);
-        hipLaunchKernelGGL(gn_apply_kernel, dim3(bpi, a.NB), dim3(256), (size_t)(2 * C + 2 * a.groups) * sizeof(float), ctx.stream, a.X0, a.X1,
-                           a.X0lo, a.X1lo, a.C0, a.C1, a.HW, rpb, part, nchunks, a.groups, a.eps, a.gamma, a.beta, a.silu ? 1 : 0, a.Y);
+#define GN_APPLY(LO_, SILU_) hipLaunchKernelGGL((gn_apply_kernel<LO_, SILU_>), dim3(bpi, a.NB), dim3(256), (size_t)(2 * C + 2 * a.groups) * sizeof(float), ctx.stream, \
+                                                a.X0, a.X1, a.X0lo, a.X1lo, a.C0, a.C1, a.HW, rpb, part, nchunks, a.groups, a.eps, a.gamma, a.beta, a.Y)
+        const bool lo = a.X0lo || a.X1lo;
+        if (lo) { if (a.silu) GN_APPLY(true, true); else GN_APPLY(true, false); }
+        else    { if (a.silu) GN_APPLY(false, true); else GN_APPLY(false, false); }
+#undef GN_APPLY
     }
     HIP_CHECK(hipGetLastError());
 }
