@@ -203,7 +203,7 @@ __global__ void repack_kernel(RepackDev a)
         int row = o;
         if (a.geglu_half > 0) {
             int j = o < a.geglu_half ? o : o - a.geglu_half;
-            row = a.geglu_pair ? 2 * j + (o < a.geglu_half ? 0 : 1) : 32 * (j >> 4) + (j & 15) + (o < a.geglu_half ? 0 : 16);
+            row = a.geglu_pair ? 4 * (j >> 1) + (j & 1) + (o < a.geglu_half ? 0 : 2) : 32 * (j >> 4) + (j & 15) + (o < a.geglu_half ? 0 : 16);
         }
         // K order of a 3x3 weight row: 64-channel chunks outermost, then the 9 taps, then the channel inside the chunk
         // (all taps of a chunk are consecutive K-tiles, so the im2col re-reads of an activation line hit L2; kernels.h)

@@ -228,7 +228,7 @@ __global__ void gemm_naive_kernel(GemmDev p)
         // weight rows: GEGLU weights are interleaved in 16-blocks: out col j -> value row 32*(j/16)+j%16, gate row +16
         int wrow = n, grow = 0;
         if (p.epi == EPI_GEGLU) { wrow = 32 * (n >> 4) + (n & 15); grow = wrow + 16; }
-        if (p.epi == EPI_GEGLU_PAIR) { wrow = 2 * n; grow = 2 * n + 1; }
+        if (p.epi == EPI_GEGLU_PAIR) { wrow = 4 * (n >> 1) + (n & 1); grow = wrow + 2; }   // rows 4q..4q+3 = value_2q, value_2q+1, gate_2q, gate_2q+1
         float s = 0.f, sg = 0.f;
         for (int tap = 0; tap < p.taps; ++tap) {
             long long pix; bool ok = true;
@@ -308,7 +308,7 @@ bool gemm_mfma_supported(const GemmArgs& a)
     if (a.lda0 % 8 || (a.C1 && a.lda1 % 8)) return false;          // 16-B aligned source chunks
     if (a.Npad % 128 && a.Npad % 160) return false;
     if (a.epi == EPI_GEGLU && (a.N % 64 || a.Npad % 128)) return false;
-    if (a.epi == EPI_GEGLU_PAIR) return false;   // pairwise layout: gemm_big.hip only
+    if (a.epi == EPI_GEGLU_PAIR) return false;   // in-fours layout: gemm_big.hip only
     if ((a.epi == EPI_STD || a.epi == EPI_GEGLU) && (a.ldd % 4 || (a.R && a.ldr % 4))) return false;
     if ((reinterpret_cast<uintptr_t>(a.A0) | reinterpret_cast<uintptr_t>(a.W)) & 15) return false;
     if ((a.sA | a.sW) % 8 || (a.sD | a.sR) % 4) return false;

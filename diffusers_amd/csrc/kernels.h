@@ -58,7 +58,7 @@ enum GemmEpilogue {
     EPI_NCHW_F32 = 2,  // Df[(nb*N + n)*HoWo + pix] = acc + bias          (UNet / VAE graph output)
     EPI_IMAGE = 3,     // Df[m*N + n] = clamp((acc + bias)/2 + 0.5, 0, 1)   (decode_latents post-processing)
     EPI_TRANS = 4,     // D[n*ldd + m] = half(alpha*acc + bias[n])
-    EPI_GEGLU_PAIR = 5 // as EPI_GEGLU with weight rows interleaved pairwise: row 2j = value_j, row 2j+1 = gate_j (gemm_big.hip)
+    EPI_GEGLU_PAIR = 5 // as EPI_GEGLU with weight rows interleaved in fours: rows 4q..4q+3 = value_2q, value_2q+1, gate_2q, gate_2q+1 (gemm_big.hip)
 };
 
 struct GemmArgs {
@@ -170,7 +170,7 @@ struct RepackArgs {
     int i0 = 0;                                // channel offset inside the tap where this source starts
     int Kdst = 0;                              // dst row length
     int geglu_half = 0;                        // >0: row o -> interleaved row (16-block value/gate), value = geglu_half
-    int geglu_pair = 0;                        // with geglu_half: pairwise interleave instead (value_j -> 2j, gate_j -> 2j+1)
+    int geglu_pair = 0;                        // with geglu_half: interleave in fours instead (value_j -> 4(j/2) + j%2, gate_j -> that + 2)
     int src_i0 = 0, src_I = 0;                 // copy only source channels [src_i0, src_i0 + src_I) (src_I = 0: all I of them)
     int dst_f32 = 0;                           // fp32 engine: dst is float [rows][Kdst]
 };

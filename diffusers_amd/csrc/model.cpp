@@ -70,7 +70,7 @@ DevLinear WeightBuilder::linear(const std::vector<std::string>& names, const std
     SDE_REQUIRE(Ipad >= I, SDE_ERR_MODEL, "cin_pad smaller than Cin for " + names[0]);
     if (ctx.f32) geglu = false;   // fp32 engine: no fused GEGLU epilogue, rows stay in file order
     L.taps = kh * kw; L.Cin = Ipad; L.K = L.taps * Ipad; L.N = N; L.Npad = gemm_npad(N); L.geglu = geglu;
-    // wide GEGLU projections run on the 256x320 kernel, which wants value/gate of a column in one lane: pairwise interleave
+    // wide GEGLU projections run on the 256x320 kernel, which wants value/gate of a column in one lane: interleave in fours (value, value, gate, gate)
     L.geglu_pair = geglu && N % 320 == 0 && L.K % 64 == 0 && L.taps == 1;
     const size_t wbytes = (size_t)L.Npad * L.K * ctx.esize();
     L.W = (half_t*)dmalloc(wbytes);

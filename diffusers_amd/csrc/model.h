@@ -33,7 +33,7 @@ struct DevLinear {
     half_t* W = nullptr;
     float* bias = nullptr;
     int N = 0, Npad = 0, K = 0, taps = 1, Cin = 0;  // Cin = (padded) channels per tap
-    bool geglu = false, geglu_pair = false;   // geglu_pair: pairwise value/gate row interleave (EPI_GEGLU_PAIR)
+    bool geglu = false, geglu_pair = false;   // geglu_pair: value/gate rows interleaved in fours (EPI_GEGLU_PAIR)
     bool gelu_tanh = false;                   // GEGLU with FastGelu's tanh form (optimizer-fused model dirs)
 };
 struct DevNorm { float* gamma = nullptr; float* beta = nullptr; int C = 0; };
