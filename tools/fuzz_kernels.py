@@ -38,12 +38,14 @@ def main():
             cin = int(rng.choice([64, 128, 192, 320, 640, 24]))
             cout = int(rng.choice([160, 320, 128, 256, 480, 640, 4, 40]))
             H, W = int(rng.integers(1, 34)), int(rng.integers(1, 34))
+            if rng.random() < 0.4:   # whole 16 x 16 patches (8 x 8 source patches under upsampling): the halo kernel's domain
+                H, W = int(rng.choice([8, 16, 32, 48])), int(rng.choice([8, 16, 32, 48]))
             NB = int(rng.integers(1, 4))
             stride = int(rng.choice([1, 1, 2])) if k == 3 else 1
             ups = int(rng.choice([0, 0, 1, 2])) if (k == 3 and stride == 1) else 0
             if ups == 2 and (H < 2 or W < 2):
                 ups = 1
-            kern = int(rng.choice([0, 0, 2, 3]))
+            kern = int(rng.choice([0, 0, 2, 3, 4, 5, 5]))   # 4 / 5: the 128x160 linear and halo 3x3 kernels where they support the case
             x = rng.standard_normal((NB, H, W, cin)).astype(np.float32)
             w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
             b = rng.standard_normal(cout).astype(np.float32)
