@@ -27,7 +27,9 @@ typedef enum sde_status {
     SDE_ERR_CONFIG = 3,           /* pyke-diffusers.toml problems, "bad framework" (impl_main.rs:113-122) */
     SDE_ERR_MODEL = 4,            /* ONNX parse / weight-binding failure */
     SDE_ERR_DEVICE = 5,           /* HIP runtime error, no GPU, extension built for another arch */
-    SDE_ERR_SCHEDULER = 6,        /* scheduler misuse that panics in the reference (euler_discrete.rs:140,181) */
+    SDE_ERR_SCHEDULER = 6,        /* scheduler misuse that panics in the reference (euler_discrete.rs:140,181); also an EMPTY schedule
+                                   * (DDIM with one inference step: ddim.rs:184 yields n - 1 timesteps), where the reference runs no step
+                                   * and decodes the scaled initial noise -- refused here rather than returned as an image */
     SDE_ERR_CANCELLED = 7,        /* a callback returned 0 (reference: `break`, impl_txt2img.rs:319-321) */
     SDE_ERR_EXCHANGE = 8          /* the CFG-pair exchange hook reported a failure (no counterpart in the reference) */
 } sde_status;

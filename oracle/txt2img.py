@@ -57,4 +57,6 @@ def run(unet: Callable[[np.ndarray, float, np.ndarray], np.ndarray], scheduler, 
         latents = scheduler.step(eps, t, latents, nz)                              # :303-304
         preds.append(eps)
         lats.append(latents.copy())
-    return dict(timesteps=ts[start_step:], noise_pred=np.stack(preds), latents=np.stack(lats), final=latents)
+    # a schedule can be empty (the reference's DDIM with one inference step yields no timesteps): nothing runs, the latents stay
+    empty = np.zeros((0,) + latents.shape, np.float32)
+    return dict(timesteps=ts[start_step:], noise_pred=np.stack(preds) if preds else empty, latents=np.stack(lats) if lats else empty, final=latents)
