@@ -187,6 +187,10 @@ def test_txt2img_size_check_and_callbacks(pipe):
     bad = StableDiffusionTxt2ImgOptions(height=100, width=128, text_embeddings=ehs, batch_size=1, steps=2)
     with pytest.raises(_lib.SdeError, match="divisible by 8"):
         bad.run(pipe, sch, skip_decode=True)
+    # an empty schedule (DDIM, one inference step: ddim.rs:184 yields n - 1 timesteps) is refused, not decoded as noise (sdengine.h)
+    one = StableDiffusionTxt2ImgOptions(height=128, width=128, text_embeddings=ehs, batch_size=1, steps=1, seed=1)
+    with pytest.raises(_lib.SdeError, match="no timesteps"):
+        one.run(pipe, N.BY_NAME["ddim"].stable_diffusion_v1_optimized_default(), skip_decode=True)
     seen = []
     o = StableDiffusionTxt2ImgOptions(height=128, width=128, text_embeddings=ehs, batch_size=1, steps=6, seed=1)
     o.callback_progress(2, lambda i, t: (seen.append(i) or True) and i < 2)   # stop after step 2
