@@ -356,6 +356,78 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(GemmDev p)
         half_t* D = p.D + zD;
         half_t* Dlo = (LO && p.Dlo) ? p.Dlo + zD : nullptr;
         const bool rvec_ok = R && (p.ldr & 7) == 0;
+        if constexpr (LO) {
+            if (R && rvec_ok && vec_ok && (p.N & 7) == 0) {
+                // Split-fp16 residual through LDS, two steps ahead.  Loaded into registers per 16-row step (below) every step pays an HBM
+                // round trip in series: eight per wave, with 656 KB per CU to move (R hi + lo in, D hi + lo out) the epilogue of the
+                // K = 640 shortcut / proj_out GEMMs ran at a third of the HBM rate.  Here each lane's chunks of step s+2 go global -> LDS by
+                // buffer_load ... lds into a two-slot ring behind the fp32 staging rows of the wave's slice while step s is added, split
+                // and stored.  A lane reads back exactly the chunks it fetched (same id -> (row, chunk) map), so the only ordering needed
+                // is its own counted vmcnt: the queue behind R(s) holds the stores of step s-1 (a wave-uniformly skipped store only
+                // shortens it) and the K pieces of R(s+1), so "at most K outstanding" means R(s) has landed.
+                constexpr int STG = 16 * PITCH, SLOT = 2 * NI * 1024;
+                static_assert(RG == 1 && STG + 2 * SLOT <= smem_bytes(NT) / 8, "residual ring must fit the wave's LDS slice");
+                const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc((void*)R, 0, OOB, RSRC_FLAGS);
+                const __amdgpu_buffer_rsrc_t rRl = __builtin_amdgcn_make_buffer_rsrc((void*)(Rlo ? Rlo : R), 0, OOB, RSRC_FLAGS);
+                const bool haslo = Rlo != nullptr;
+                auto issue_R = [&](int ms, int slot) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int id = min(lane + 64 * i, NCH - 1), row = id / CH, ch = id - row * CH;
+                        const int m = min(m0 + wr * 128 + ms * 16 + row, p.M - 1), n = min(n0 + wc * WN + ch * 8, p.N - 8);
+                        const unsigned voff = (unsigned)(m * p.ldr + n) * 2u;
+                        char* dst = wlds + STG + slot * SLOT + i * 1024;
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rR, LDS_PTR(dst), 16, voff, 0, 0, 0);
+                        if (haslo) __builtin_amdgcn_raw_ptr_buffer_load_lds(rRl, LDS_PTR(dst + NI * 1024), 16, voff, 0, 0, 0);
+                    }
+                };
+                issue_R(0, 0);
+                issue_R(1, 1);
+#pragma unroll
+                for (int ms = 0; ms < 8; ++ms) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        floatx4 o;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = acc[nt][ms][r] * p.alpha + bv[nt][r];
+                        *(floatx4*)(wlds + fr * PITCH + (nt * 16 + 4 * fg) * 4) = o;
+                    }
+                    if (ms == 7) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    else if (haslo) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    static_assert(NI == 3, "counted waits above assume three pieces per tensor and step");
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    const char* slot = wlds + STG + (ms & 1) * SLOT;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) {
+                        const int id = lane + 64 * i, idc = min(id, NCH - 1), row = idc / CH, ch = idc - row * CH;
+                        const int m = m0 + wr * 128 + ms * 16 + row, n = n0 + wc * WN + ch * 8;
+                        const floatx4 lo = *(const floatx4*)(wlds + row * PITCH + ch * 32), hi = *(const floatx4*)(wlds + row * PITCH + ch * 32 + 16);
+                        const half8 rr = *(const half8*)(slot + i * 1024 + lane * 16);
+                        half8 rl;
+                        if (haslo) rl = *(const half8*)(slot + (NI + i) * 1024 + lane * 16);
+                        const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        half8 v, vl;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            float x = f[e] + (float)rr[e];
+                            if (haslo) x += (float)rl[e];
+                            v[e] = (half_t)x;
+                            vl[e] = (half_t)(x - (float)v[e]);
+                        }
+                        if (id < NCH && m < p.M && n < p.N) {
+                            *(half8*)(D + (long long)m * p.ldd + n) = v;
+                            if (Dlo) *(half8*)(Dlo + (long long)m * p.ldd + n) = vl;
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_wave_barrier();
+                    if (ms + 2 < 8) issue_R(ms + 2, ms & 1);
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int ms = 0; ms < 8 / RG; ++ms) {
             // residual chunks of these rows, in flight while the accumulators go through LDS
