@@ -52,9 +52,14 @@ class Txt2ImgOpts(C.Structure):
                 ("trace_rows", C.c_int), ("step_noise_rows", C.c_int), ("start_step", C.c_int)]
 
 
+class StepOutput(C.Structure):
+    _fields_ = [("prev_sample", C.c_void_p), ("pred_original_sample", C.c_void_p), ("derivative", C.c_void_p),
+                ("has_pred_original_sample", C.c_int), ("has_derivative", C.c_int)]
+
+
 class RunStats(C.Structure):
     _fields_ = [("unet_calls", C.c_int), ("total_ms", C.c_float), ("unet_ms", C.c_float), ("vae_ms", C.c_float),
-                ("host_enqueue_ms", C.c_float)]
+                ("host_enqueue_ms", C.c_float), ("unet_graph_launches", C.c_int)]
 
 
 class KernelStat(C.Structure):
@@ -97,6 +102,7 @@ SYMBOLS = {
     "sde_scheduler_scale_model_input": (_i, [_vp, _vp, C.c_size_t, _f, _vp]),
     "sde_scheduler_step": (_i, [_vp, _vp, _f, _vp, _vp, C.c_size_t, _vp]),
     "sde_scheduler_add_noise": (_i, [_vp, _vp, _vp, C.c_size_t, _f, _vp]),
+    "sde_scheduler_step_output": (_i, [_vp, _vp, _f, _vp, _vp, C.c_size_t, C.POINTER(StepOutput)]),
     "sde_txt2img_opts_default": (None, [C.POINTER(Txt2ImgOpts)]),
     "sde_txt2img_run": (_i, [_vp, _vp, C.POINTER(Txt2ImgOpts), _vp, C.POINTER(RunStats)]),
     "sde_rng_standard_normal": (_i, [C.c_uint64, C.c_uint64, _vp, C.c_size_t]),
@@ -106,9 +112,9 @@ SYMBOLS = {
     "sde_profile_reset": (_i, [_vp]),
     "sde_profile_get": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
     "sde_synchronize": (_i, [_vp]),
-    "sde_test_conv": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp]),
-    "sde_test_conv_res": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp]),
-    "sde_test_attention": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sde_test_conv": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, C.c_size_t]),
+    "sde_test_conv_res": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, C.c_size_t]),
+    "sde_test_attention": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t]),
 }
 
 _lib = None

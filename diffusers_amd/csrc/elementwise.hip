@@ -238,7 +238,7 @@ struct StepDev {
     float c[12]; int clip, dpm_algo;
     float* hist[4]; int nhist; float lms_c[4];
     float next_scale; half_t* next_input; int Cpad, next_f32;
-    float* eps_out;
+    float* eps_out; float* x0_out; float* deriv_out;
 };
 
 __global__ void cfg_step_kernel(StepDev a)
@@ -262,12 +262,16 @@ __global__ void cfg_step_kernel(StepDev a)
             float pred = s - a.c[0] * e;
             float d = (s - pred) / a.c[0];
             prev = s + d * a.c[1];
+            if (a.x0_out) a.x0_out[i] = pred;
+            if (a.deriv_out) a.deriv_out[i] = d;
         } break;
         case STEP_EULER_A: { // euler_ancestral_discrete.rs:194-204 ; c0 = sigma_from, c1 = dt, c2 = sigma_up
             float pred = s - a.c[0] * e;
             float d = (s - pred) / a.c[0];
             prev = s + d * a.c[1];
             prev = prev + a.noise[i] * a.c[2];
+            if (a.x0_out) a.x0_out[i] = pred;
+            if (a.deriv_out) a.deriv_out[i] = d;
         } break;
         case STEP_DPM1:
         case STEP_DPM2M:
@@ -309,6 +313,7 @@ __global__ void cfg_step_kernel(StepDev a)
             else { mo = a.c[0] * mo + a.c[1] * s; x0 = a.c[0] * s - a.c[1] * mo; }
             if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
             prev = a.c[2] * x0 + a.c[3] * mo;
+            if (a.x0_out) a.x0_out[i] = x0;
         } break;
         case STEP_DDPM: {    // ddpm.rs:203-232 ; c0 = sqrt(alpha_t), c1 = sqrt(beta_t), c2 = x0 coeff, c3 = sample coeff, c4 = noise coeff (0 at pos 0)
             float x0;
@@ -317,6 +322,7 @@ __global__ void cfg_step_kernel(StepDev a)
             if (a.clip) x0 = fminf(fmaxf(x0, -1.0f), 1.0f);
             prev = a.c[2] * x0 + a.c[3] * s;
             if (a.noise) prev = prev + a.c[4] * a.noise[i];
+            if (a.x0_out) a.x0_out[i] = x0;
         } break;
         default: {           // STEP_LMS ; c0 = sigma ; lms_c[k] multiplies derivative (i-k); hist[0] receives the new derivative
             float pred = s - a.c[0] * e;
@@ -324,6 +330,8 @@ __global__ void cfg_step_kernel(StepDev a)
             prev = s + a.lms_c[0] * d;
             for (int k = 1; k < a.nhist; ++k) prev = prev + a.lms_c[k] * a.hist[k][i];
             a.hist[0][i] = d;
+            if (a.x0_out) a.x0_out[i] = pred;
+            if (a.deriv_out) a.deriv_out[i] = d;
         } break;
         }
         a.latents[i] = prev;
@@ -353,7 +361,7 @@ void launch_cfg_step(const LaunchCtx& ctx, const StepArgs& s)
     for (int i = 0; i < 12; ++i) a.c[i] = s.c[i];
     a.clip = s.clip; a.dpm_algo = s.dpm_algo;
     for (int i = 0; i < 4; ++i) { a.hist[i] = s.hist[i]; a.lms_c[i] = s.lms_c[i]; }
-    a.nhist = s.nhist; a.next_scale = s.next_input_scale; a.next_input = s.next_input; a.Cpad = s.Cpad; a.eps_out = s.eps_out; a.next_f32 = s.next_input_f32;
+    a.nhist = s.nhist; a.next_scale = s.next_input_scale; a.next_input = s.next_input; a.Cpad = s.Cpad; a.eps_out = s.eps_out; a.next_f32 = s.next_input_f32; a.x0_out = s.x0_out; a.deriv_out = s.deriv_out;
     SDE_REQUIRE(!((s.kind == STEP_EULER_A) && !s.noise), SDE_ERR_INVALID_ARGUMENT, "cfg_step: Euler-a needs a noise tensor");
     const long long per = (long long)s.B * s.C * s.H * s.W;
     const double bytes = per * ((s.cfg ? 8.0 : 4.0) + 8.0 + (s.noise ? 4.0 : 0.0) + (s.next_input ? (s.cfg ? 4.0 : 2.0) : 0.0) + 4.0 * s.nhist);

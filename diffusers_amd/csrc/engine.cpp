@@ -160,6 +160,8 @@ struct sde_engine {
     DevBuf t_dev;                      // the UNet call's (truncated) timestep, read by the time-embedding kernel
     std::vector<UnetGraph> graphs;     // captured UNet calls (unet_run)
     bool use_graphs = true;            // SDE_GRAPH=0: launch by launch
+    int capture_fault_inject = 0;      // SDE_TEST_CAPTURE_FAULT=n: the next n graph captures fail inside (fault injection for the fallback test)
+    std::string graph_fallback_reason; // why use_graphs was turned off at run time (empty: it was not)
     long long split_max_hw = 1LL << 40;   // UNet trunk as split fp16 at every level (Exec::split); SDE_SPLIT_MAX_HW: tuning hook (0 = off)
     std::vector<half_t*> kv_ptrs;
     std::mutex mu;  // one forward at a time per engine (reference: Session is Send+Sync; here calls serialize)
@@ -216,7 +218,8 @@ static void setup_kv(sde_engine* e, int N, int S)
 }
 
 // runs the UNet on device buffers; sizes the arena with a dry pass when the shape changes
-static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w, float t, const half_t* ehs_h, int S, bool fill_kv,
+// returns true when the call went out as one hipGraph launch
+static bool unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w, float t, const half_t* ehs_h, int S, bool fill_kv,
                      float* out)
 {
     SDE_REQUIRE(e->has_unet, SDE_ERR_MODEL, "engine was created without a UNet");
@@ -238,7 +241,7 @@ static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w,
         e->unet.forward(ex, x_packed, N, h, w, e->t_dev.as<float>(), ehs_h, S, e->kv_ptrs.data(), fill_kv, out);
     };
     // the first call of a run (fill_kv) and profiled passes (events between the launches) go out launch by launch
-    if (!e->use_graphs || fill_kv || e->prof.enabled) { run_plain(); return; }
+    if (!e->use_graphs || fill_kv || e->prof.enabled) { run_plain(); return false; }
     const void* ptrs[6] = {x_packed, ehs_h, out, e->arena_buf.p, e->kvbuf.p, e->t_dev.p};
     UnetGraph* g = nullptr;
     for (auto& c : e->graphs)
@@ -249,23 +252,39 @@ static void unet_run(sde_engine* e, const half_t* x_packed, int N, int h, int w,
         UnetGraph ng;
         ng.key = key; std::copy(ptrs, ptrs + 6, ng.ptrs);
         hipError_t err = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+        bool threw = false;
+        std::string why;
         if (err == hipSuccess) {
-            try { run_plain(); } catch (...) { hipGraph_t junk = nullptr; (void)hipStreamEndCapture(e->stream, &junk); if (junk) (void)hipGraphDestroy(junk); throw; }
-            err = hipStreamEndCapture(e->stream, &ng.graph);
+            // Anything run_plain() throws while the stream is capturing (a HIP_CHECK on a capture-illegal call: a kernel instance's
+            // first-time hipFuncSetAttribute, a DevBuf::ensure that has to grow ...) must not reach the caller with the stream still
+            // capturing and use_graphs still set: every later call of this shape would fail the same way.
+            try {
+                if (e->capture_fault_inject > 0) { --e->capture_fault_inject; throw SdeError(SDE_ERR_DEVICE, "injected capture fault (SDE_TEST_CAPTURE_FAULT)"); }
+                run_plain();
+            } catch (const std::exception& ex) { threw = true; why = ex.what(); } catch (...) { threw = true; why = "unknown exception"; }
+            hipError_t end = hipStreamEndCapture(e->stream, &ng.graph);
+            if (threw) err = hipErrorStreamCaptureInvalidated;
+            else err = end;
             if (err == hipSuccess) err = hipGraphInstantiate(&ng.exec, ng.graph, nullptr, nullptr, 0);
         }
-        if (err != hipSuccess) {   // no graphs on this runtime: stay on plain launches
+        if (err != hipSuccess) {   // no graph for this call: stay on plain launches from here on
             (void)hipGetLastError();
             ng.reset();
             e->use_graphs = false;
-            run_plain();
-            return;
+            e->graph_fallback_reason = threw ? why : std::string(hipGetErrorString(err));
+            run_plain();           // uncaptured replay; if THIS throws the error is real and goes to the caller
+            return false;
         }
-        if (e->graphs.size() >= 4) { e->graphs.front().reset(); e->graphs.erase(e->graphs.begin()); }
+        if (e->graphs.size() >= 4) {
+            // the oldest graph may still be executing (launched by an earlier step of this stream)
+            HIP_CHECK(hipStreamSynchronize(e->stream));
+            e->graphs.front().reset(); e->graphs.erase(e->graphs.begin());
+        }
         e->graphs.push_back(ng);
         g = &e->graphs.back();
     }
     HIP_CHECK(hipGraphLaunch(g->exec, e->stream));
+    return true;
 }
 
 static void vae_run(sde_engine* e, const half_t* x_packed, int B, int h, int w, int epi, float* out)
@@ -419,6 +438,7 @@ static sde_status engine_create_impl(const std::string& unet_path, const std::st
         if (const char* sk = getenv("SDE_SPLITK")) e->ctx.splitk_force = atoi(sk);   // tuning hook (0 = heuristic, 1 = off)
         if (const char* sp = getenv("SDE_SPLIT_MAX_HW")) { if (!e->ctx.f32) e->split_max_hw = atoll(sp); }
         if (const char* gr = getenv("SDE_GRAPH")) e->use_graphs = atoi(gr) != 0;
+        if (const char* cf = getenv("SDE_TEST_CAPTURE_FAULT")) e->capture_fault_inject = atoi(cf);
         e->wb.ctx = e->ctx; e->wb.ctx.prof = nullptr;
         if (o.load_unet && !unet_path.empty()) {
             OnnxModel m; WeightMap w;
@@ -772,36 +792,61 @@ sde_status sde_scheduler_scale_model_input(sde_scheduler* s, const float* sample
     });
 }
 
+static void scheduler_step_impl(sde_scheduler* s, const float* model_output, float timestep, const float* sample, const float* noise, size_t n,
+                                sde_step_output* o)
+{
+    SDE_REQUIRE(s && model_output && sample && o && o->prev_sample && n > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
+    require_device();
+    StepPlan p;
+    s->plan(timestep, p);
+    SDE_REQUIRE(!p.needs_noise || noise, SDE_ERR_INVALID_ARGUMENT, "this scheduler step needs a noise tensor");
+    // which Option<> fields of SchedulerStepOutput the step fills: pred_original_sample by Euler, Euler-a, DDIM, DDPM
+    // (euler_discrete.rs:216-220, euler_ancestral_discrete.rs:206-210, ddim.rs:246-250, ddpm.rs:234-238), none by DPM-Solver
+    // (dpm_solver_multistep.rs:379); `derivative` is computed by the Euler family (euler_discrete.rs:210) and on offer here
+    const bool has_x0 = p.kind == STEP_EULER || p.kind == STEP_EULER_A || p.kind == STEP_DDIM || p.kind == STEP_DDPM || p.kind == STEP_LMS;
+    const bool has_d = p.kind == STEP_EULER || p.kind == STEP_EULER_A || p.kind == STEP_LMS;
+    TmpDev t; LaunchCtx ctx;
+    StepArgs a;
+    a.kind = p.kind; a.pred = p.pred; a.B = 1; a.C = 1; a.H = 1; a.W = (int)n; a.cfg = 0;
+    a.model_out = t.up(model_output, n); a.latents = t.up(sample, n); a.noise = p.needs_noise ? t.up(noise, n) : nullptr;
+    if (o->pred_original_sample && has_x0) a.x0_out = t.up(nullptr, n);
+    if (o->derivative && has_d) a.deriv_out = t.up(nullptr, n);
+    for (int i = 0; i < 12; ++i) a.c[i] = p.c[i];
+    a.clip = p.clip; a.nhist = p.nhist; a.dpm_algo = p.dpm_algo;
+    for (int i = 0; i < 4; ++i) a.lms_c[i] = p.lms_c[i];
+    if (p.nhist > 0 || s->kind == SDE_SCHED_LMS) {
+        if (s->mirror_hist_n != n) {
+            for (float* q : s->mirror_hist) if (q) (void)hipFree(q);
+            s->mirror_hist.assign(4, nullptr);
+            for (auto& q : s->mirror_hist) { HIP_CHECK(hipMalloc((void**)&q, n * 4)); HIP_CHECK(hipMemset(q, 0, n * 4)); }
+            s->mirror_hist_n = n;
+        }
+        for (int i = 0; i < 4; ++i) a.hist[i] = s->mirror_hist[(size_t)i];
+    }
+    launch_cfg_step(ctx, a);
+    HIP_CHECK(hipMemcpy(o->prev_sample, a.latents, n * 4, hipMemcpyDeviceToHost));
+    if (a.x0_out) HIP_CHECK(hipMemcpy(o->pred_original_sample, a.x0_out, n * 4, hipMemcpyDeviceToHost));
+    if (a.deriv_out) HIP_CHECK(hipMemcpy(o->derivative, a.deriv_out, n * 4, hipMemcpyDeviceToHost));
+    o->has_pred_original_sample = has_x0 ? 1 : 0;
+    o->has_derivative = has_d ? 1 : 0;
+    if (!s->mirror_hist.empty()) s->rotate_history(p, s->mirror_hist.data());
+    s->advance(p);
+}
+
 sde_status sde_scheduler_step(sde_scheduler* s, const float* model_output, float timestep, const float* sample, const float* noise, size_t n,
                               float* prev_sample)
 {
     return guarded([&] {
-        SDE_REQUIRE(s && model_output && sample && prev_sample && n > 0, SDE_ERR_INVALID_ARGUMENT, "bad argument");
-        require_device();
-        StepPlan p;
-        s->plan(timestep, p);
-        SDE_REQUIRE(!p.needs_noise || noise, SDE_ERR_INVALID_ARGUMENT, "this scheduler step needs a noise tensor");
-        TmpDev t; LaunchCtx ctx;
-        StepArgs a;
-        a.kind = p.kind; a.pred = p.pred; a.B = 1; a.C = 1; a.H = 1; a.W = (int)n; a.cfg = 0;
-        a.model_out = t.up(model_output, n); a.latents = t.up(sample, n); a.noise = p.needs_noise ? t.up(noise, n) : nullptr;
-        for (int i = 0; i < 12; ++i) a.c[i] = p.c[i];
-        a.clip = p.clip; a.nhist = p.nhist; a.dpm_algo = p.dpm_algo;
-        for (int i = 0; i < 4; ++i) a.lms_c[i] = p.lms_c[i];
-        if (p.nhist > 0 || s->kind == SDE_SCHED_LMS) {
-            if (s->mirror_hist_n != n) {
-                for (float* q : s->mirror_hist) if (q) (void)hipFree(q);
-                s->mirror_hist.assign(4, nullptr);
-                for (auto& q : s->mirror_hist) { HIP_CHECK(hipMalloc((void**)&q, n * 4)); HIP_CHECK(hipMemset(q, 0, n * 4)); }
-                s->mirror_hist_n = n;
-            }
-            for (int i = 0; i < 4; ++i) a.hist[i] = s->mirror_hist[(size_t)i];
-        }
-        launch_cfg_step(ctx, a);
-        HIP_CHECK(hipMemcpy(prev_sample, a.latents, n * 4, hipMemcpyDeviceToHost));
-        if (!s->mirror_hist.empty()) s->rotate_history(p, s->mirror_hist.data());
-        s->advance(p);
+        sde_step_output o{};
+        o.prev_sample = prev_sample;
+        scheduler_step_impl(s, model_output, timestep, sample, noise, n, &o);
     });
+}
+
+sde_status sde_scheduler_step_output(sde_scheduler* s, const float* model_output, float timestep, const float* sample, const float* noise, size_t n,
+                                     sde_step_output* out)
+{
+    return guarded([&] { scheduler_step_impl(s, model_output, timestep, sample, noise, n, out); });
 }
 
 sde_status sde_scheduler_add_noise(sde_scheduler* s, const float* original, const float* noise, size_t n, float timestep, float* out)
@@ -863,7 +908,11 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         sch->set_timesteps(o->steps);                         // :264
         const std::vector<float> ts = sch->timesteps;         // :269
         const int nt = (int)ts.size();
-        SDE_REQUIRE(nt > 0, SDE_ERR_SCHEDULER, "scheduler produced no timesteps");
+        // An empty schedule (the reference's DDIM with one inference step: ddim.rs:184 yields n - 1 timesteps).  The reference runs no
+        // step and decodes init_noise_sigma * latents (impl_txt2img.rs:265,272,326); in parity mode (reference_quirks, the default)
+        // so does the engine.  With the quirks off an empty schedule is a caller error.
+        const bool empty = nt == 0;
+        SDE_REQUIRE(!empty || sch->cfg.reference_quirks, SDE_ERR_SCHEDULER, "scheduler produced no timesteps");
         // per-timestep caller buffers: nt is the scheduler's count, not `steps` (DDPM: ceil(T / (T / steps)), ddpm.rs:181)
         if (o->noise_pred_out || o->latents_out) {
             const int rows = o->trace_rows > 0 ? o->trace_rows : o->steps;
@@ -878,7 +927,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
                             " timesteps (set step_noise_rows from sde_scheduler_num_timesteps)");
         }
         const int i0 = o->start_step;   // image-to-image: the loop starts inside the schedule (sdengine.h)
-        SDE_REQUIRE(i0 >= 0 && i0 < nt, SDE_ERR_INVALID_ARGUMENT, "start_step must lie inside the scheduler's timesteps");
+        SDE_REQUIRE(i0 >= 0 && (i0 < nt || (empty && i0 == 0)), SDE_ERR_INVALID_ARGUMENT, "start_step must lie inside the scheduler's timesteps");
         SDE_REQUIRE(i0 == 0 || o->init_latents, SDE_ERR_INVALID_ARGUMENT, "start_step > 0 needs init_latents (the noised image latents)");
         long long num_warmup = (long long)nt - (long long)o->steps * 1;  // :270 ; negative == usize wrap-around in release builds
         if (num_warmup < 0) num_warmup = (1LL << 62);
@@ -930,11 +979,11 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         HIP_CHECK(hipEventRecord(ev0, st));
 
         // first model input: scale_model_input(concat(latents, latents), t0)  (:273-278)
-        {
+        if (!empty) {
             float div = sch->input_scale_divisor(ts[(size_t)i0]);
             launch_pack_latents(e->ctx, d_lat, e->x_packed.as<half_t>(), B, (cfg && !half) ? 2 : 1, C, h, w, Cp, 1.0f / div);
         }
-        int unet_calls = 0;
+        int unet_calls = 0, graph_launches = 0;
         double enqueue_ms = 0.0;
         struct LaneDrain {   // nothing of the preview lane may outlive the call, whichever way it ends
             sde_engine* e;
@@ -945,8 +994,8 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         for (int i = i0; i < nt; ++i) {
             const float t = ts[(size_t)i];
             const auto tq0 = std::chrono::steady_clock::now();
-            unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, (const half_t*)(e->ehs_h.as<char>() + half_off * B * S * D * e->ctx.esize()), S, i == i0,
-                     e->model_out.as<float>() + half_off * per);                                             // :283
+            graph_launches += unet_run(e, e->x_packed.as<half_t>(), Nu, h, w, t, (const half_t*)(e->ehs_h.as<char>() + half_off * B * S * D * e->ctx.esize()), S,
+                                       i == i0, e->model_out.as<float>() + half_off * per) ? 1 : 0;                                             // :283
             enqueue_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq0).count();
             if (pending_cb) {
                 // deliver step i-1's payload while the GPU works on UNet call i.  `false` -> break (:319-321): the UNet call just
@@ -1072,6 +1121,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
             (void)hipEventElapsedTime(&a, ev0, ev1); (void)hipEventElapsedTime(&b, ev1, ev2);
             stats->unet_calls = unet_calls; stats->unet_ms = a; stats->vae_ms = b; stats->total_ms = a + b;
             stats->host_enqueue_ms = (float)enqueue_ms;
+            stats->unet_graph_launches = graph_launches;
         }
     });
 }
@@ -1105,12 +1155,22 @@ sde_status sde_synchronize(sde_engine* e)
     return guarded([&] { SDE_REQUIRE(e, SDE_ERR_INVALID_ARGUMENT, "null engine"); engine_activate(e); HIP_CHECK(hipStreamSynchronize(e->stream)); });
 }
 
+// The test hooks compute their output shape themselves and copy that many floats into a caller buffer: the caller states the
+// buffer's capacity (elements) and anything else than an exact fit is refused before the device-to-host copy.
+static void require_out_capacity(const char* fn, size_t need, size_t have, const std::string& shape)
+{
+    SDE_REQUIRE(need == have, SDE_ERR_INVALID_ARGUMENT,
+                std::string(fn) + ": the output is " + shape + " = " + std::to_string(need) + " floats, the caller's buffer holds " +
+                    std::to_string(have) + " (out_capacity)");
+}
+
 sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin, const float* w, const float* bias, int Cout,
-                         int ksize, int stride, int upsample, float* out)
+                         int ksize, int stride, int upsample, float* out, size_t out_capacity)
 {
     return guarded([&] {
         SDE_REQUIRE(e && x && w && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
         SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
+        SDE_REQUIRE(NB > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && stride >= 1 && stride <= 2, SDE_ERR_INVALID_ARGUMENT, "bad conv geometry");
         EngineLock lk(e);
         engine_activate(e);
         LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3; ctx.force_mid128 = naive == 4; ctx.force_midh = naive == 5;   // 0 fast, 1 plain, 2 / 3 / 4 / 5 force the 256x320 / 256x160 / 128x160 / halo kernel
@@ -1123,6 +1183,9 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         const int Hv = upsample ? 2 * Hi - (upsample == 2) : Hi, Wv = upsample ? 2 * Wi - (upsample == 2) : Wi;
         const int Ho = asym ? (Hi - 2) / 2 + 1 : (ksize == 3 ? (Hv - 1) / stride + 1 : Hv), Wo = asym ? (Wi - 2) / 2 + 1 : (ksize == 3 ? (Wv - 1) / stride + 1 : Wv);
         const size_t nx = (size_t)NB * Hi * Wi * Cin, nw = (size_t)Cout * Cin * taps, no = (size_t)NB * Ho * Wo * Cout;
+        // the output geometry is computed HERE; the caller states what its buffer holds and a disagreement is refused before any copy
+        require_out_capacity("sde_test_conv", no, out_capacity,
+                             "[" + std::to_string(NB) + "," + std::to_string(Ho) + "," + std::to_string(Wo) + "," + std::to_string(Cout) + "]");
         const int Npad = gemm_npad(Cout), K = taps * Cin;
         DevBuf dxf, dxh, dwf, dwh, dbias, doh, dof;
         dxf.ensure(nx * 4); dxh.ensure(nx * 2); dwf.ensure(nw * 4); dwh.ensure((size_t)Npad * K * 2); doh.ensure(no * 2); dof.ensure(no * 4);
@@ -1148,11 +1211,14 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
 }
 
 sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin, const float* w, const float* bias, int Cout,
-                             int ksize, const float* residual, int split, float* out)
+                             int ksize, const float* residual, int split, float* out, size_t out_capacity)
 {
     return guarded([&] {
         SDE_REQUIRE(e && x && w && out && residual, SDE_ERR_INVALID_ARGUMENT, "null argument");
         SDE_REQUIRE(ksize == 1 || ksize == 3, SDE_ERR_INVALID_ARGUMENT, "ksize must be 1 or 3");
+        SDE_REQUIRE(NB > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0, SDE_ERR_INVALID_ARGUMENT, "bad conv geometry");
+        require_out_capacity("sde_test_conv_res", (size_t)NB * Hi * Wi * Cout, out_capacity,
+                             "[" + std::to_string(NB) + "," + std::to_string(Hi) + "," + std::to_string(Wi) + "," + std::to_string(Cout) + "]");
         EngineLock lk(e);
         engine_activate(e);
         LaunchCtx ctx = e->ctx; ctx.f32 = false;
@@ -1193,10 +1259,13 @@ sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, i
 }
 
 sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const float* k, const float* v, int NB, int heads, int Sq, int Skv, int d,
-                              float* out)
+                              float* out, size_t out_capacity)
 {
     return guarded([&] {
         SDE_REQUIRE(e && q && k && v && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(NB > 0 && heads > 0 && Sq > 0 && Skv > 0 && d > 0, SDE_ERR_INVALID_ARGUMENT, "bad attention geometry");
+        require_out_capacity("sde_test_attention", (size_t)NB * Sq * heads * d, out_capacity,
+                             "[" + std::to_string(NB) + "," + std::to_string(Sq) + "," + std::to_string(heads * d) + "]");
         EngineLock lk(e);
         engine_activate(e);
         LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive != 0;

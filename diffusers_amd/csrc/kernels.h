@@ -199,6 +199,8 @@ struct StepArgs {
     int next_input_f32 = 0;
     int Cpad = 64;
     float* eps_out = nullptr;               // optional f32 [B,4,h,w] tap: CFG-combined model output
+    float* x0_out = nullptr;                // optional f32 [B,4,h,w]: SchedulerStepOutput::pred_original_sample (schedulers/mod.rs:111) where the step has one
+    float* deriv_out = nullptr;             // optional f32 [B,4,h,w]: the Euler family's derivative (euler_discrete.rs:210)
 };
 void launch_cfg_step(const LaunchCtx& ctx, const StepArgs& a);
 // latents -> scaled, duplicated, packed UNet input (first step / standalone scale_model_input)

@@ -158,6 +158,7 @@ class Txt2ImgResult:
     unet_ms: float = 0.0
     vae_ms: float = 0.0
     host_enqueue_ms: float = 0.0
+    unet_graph_launches: int = 0
     noise_pred: Optional[np.ndarray] = None  # [n_steps,B,4,h,w] when trace=True
     latents: Optional[np.ndarray] = None     # [n_steps,B,4,h,w] when trace=True
     final_latents: Optional[np.ndarray] = None
@@ -362,6 +363,7 @@ class StableDiffusionTxt2ImgOptions:
             raise cb_errors[0]
         res.unet_calls, res.total_ms, res.unet_ms, res.vae_ms = st.unet_calls, st.total_ms, st.unet_ms, st.vae_ms
         res.host_enqueue_ms = st.host_enqueue_ms
+        res.unet_graph_launches = st.unet_graph_launches
         if trace and res.noise_pred is not None:
             s0 = int(self.start_step)        # rows are indexed by the absolute step: the executed ones are [start_step, start_step + calls)
             res.noise_pred = res.noise_pred[s0:s0 + st.unet_calls]
@@ -441,7 +443,10 @@ class StableDiffusionImg2ImgOptions:
                              f"{lat_shape[2]}x{lat_shape[3]} (height/8 x width/8)")
         z = session.vae_encoder(2.0 * img - 1.0, draws[:n].reshape(lat_shape))
         z = (np.float32(0.18215) * z).astype(np.float32)
-        if t0 >= len(ts):                                   # strength 0: nothing to denoise
+        # timesteps[t0:] empty: nothing to denoise and no timestep to noise at, so the encoded image is decoded as it is.  That is
+        # strength 0 for every scheduler -- and, for the reference's DDIM, whose schedule has steps - 1 entries (ddim.rs:184), also
+        # every strength with int(steps * strength) == 1 (t0 == steps - 1 == len(ts)).  Parity unpinned (the reference has no img2img run).
+        if t0 >= len(ts):
             return Txt2ImgResult(images=session.decode_latents(z), unet_calls=0)
         noised = scheduler.add_noise(z, draws[n:].reshape(lat_shape), float(ts[t0]))
         import copy

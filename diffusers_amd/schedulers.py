@@ -26,6 +26,25 @@ def _f32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+class SchedulerStepOutput:
+    """schedulers/mod.rs:109-150 (accessor names kept; ``prev_sample_mean`` is None in every scheduler of the reference)."""
+
+    def __init__(self, prev_sample, pred_original_sample=None, derivative=None):
+        self._prev, self._x0, self._d = prev_sample, pred_original_sample, derivative
+
+    def prev_sample(self):
+        return self._prev
+
+    def pred_original_sample(self):
+        return self._x0
+
+    def prev_sample_mean(self):
+        return None
+
+    def derivative(self):
+        return self._d
+
+
 class DiffusionScheduler:
     KIND = -1
 
@@ -119,6 +138,18 @@ class DiffusionScheduler:
         _lib.check(_lib.lib().sde_scheduler_step(self._h, mo.ctypes.data, float(timestep), s.ctypes.data,
                                                  nz.ctypes.data if nz is not None else None, s.size, out.ctypes.data))
         return out
+
+    def step_output(self, model_output, timestep, sample, noise=None) -> "SchedulerStepOutput":
+        """``step`` returning the whole ``SchedulerStepOutput`` (schedulers/mod.rs:109-150): ``pred_original_sample`` is None where
+        the reference's step leaves it None (DPM-Solver); ``derivative`` (the Euler family's) is offered although the reference
+        never fills that field."""
+        mo, s = _f32(model_output), _f32(sample)
+        nz = _f32(noise) if noise is not None else None
+        prev, x0, d = np.empty_like(s), np.empty_like(s), np.empty_like(s)
+        o = _lib.StepOutput(prev.ctypes.data, x0.ctypes.data, d.ctypes.data, 0, 0)
+        _lib.check(_lib.lib().sde_scheduler_step_output(self._h, mo.ctypes.data, float(timestep), s.ctypes.data,
+                                                        nz.ctypes.data if nz is not None else None, s.size, C.byref(o)))
+        return SchedulerStepOutput(prev, x0 if o.has_pred_original_sample else None, d if o.has_derivative else None)
 
     def add_noise(self, original_samples, noise, timestep) -> np.ndarray:
         x, nz = _f32(original_samples), _f32(noise)

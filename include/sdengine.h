@@ -27,9 +27,10 @@ typedef enum sde_status {
     SDE_ERR_CONFIG = 3,           /* pyke-diffusers.toml problems, "bad framework" (impl_main.rs:113-122) */
     SDE_ERR_MODEL = 4,            /* ONNX parse / weight-binding failure */
     SDE_ERR_DEVICE = 5,           /* HIP runtime error, no GPU, extension built for another arch */
-    SDE_ERR_SCHEDULER = 6,        /* scheduler misuse that panics in the reference (euler_discrete.rs:140,181); also an EMPTY schedule
-                                   * (DDIM with one inference step: ddim.rs:184 yields n - 1 timesteps), where the reference runs no step
-                                   * and decodes the scaled initial noise -- refused here rather than returned as an image */
+    SDE_ERR_SCHEDULER = 6,        /* scheduler misuse that panics in the reference (euler_discrete.rs:140,181).  An EMPTY schedule (DDIM
+                                   * with one inference step: ddim.rs:184 yields n - 1 timesteps) is NOT an error in parity mode
+                                   * (sde_sched_cfg.reference_quirks = 1, the default): as in the reference no step runs and
+                                   * init_noise_sigma * latents are decoded; with reference_quirks = 0 it is refused with this status */
     SDE_ERR_CANCELLED = 7,        /* a callback returned 0 (reference: `break`, impl_txt2img.rs:319-321) */
     SDE_ERR_EXCHANGE = 8          /* the CFG-pair exchange hook reported a failure (no counterpart in the reference) */
 } sde_status;
@@ -172,6 +173,23 @@ sde_status sde_scheduler_step(sde_scheduler* s, const float* model_output, float
                               const float* noise, size_t n, float* prev_sample);
 sde_status sde_scheduler_add_noise(sde_scheduler* s, const float* original, const float* noise, size_t n,
                                    float timestep, float* out);
+/* `SchedulerStepOutput` (schedulers/mod.rs:109-150): the same step with the struct's optional fields on request.  prev_sample is
+ * required; pred_original_sample / derivative may be NULL (not wanted).  On return has_pred_original_sample says whether the
+ * reference's step fills `pred_original_sample: Some(..)` -- Euler (euler_discrete.rs:216-220), Euler-a
+ * (euler_ancestral_discrete.rs:206-210), DDIM (ddim.rs:246-250), DDPM (ddpm.rs:234-238) and LMS do, DPM-Solver does not
+ * (dpm_solver_multistep.rs:379) -- and the buffer, if given, then holds it (after clipping, where clip_sample applies).
+ * `derivative` is (sample - pred_original_sample) / sigma of the Euler family (euler_discrete.rs:210; LMS: the derivative it
+ * stores): the reference computes it and leaves the struct's field None, here it is on offer (has_derivative = 1 for those kinds).
+ * `prev_sample_mean` is None in every scheduler of the reference and has no counterpart. */
+typedef struct sde_step_output {
+    float* prev_sample;            /* f32 [n], required */
+    float* pred_original_sample;   /* f32 [n] or NULL */
+    float* derivative;             /* f32 [n] or NULL */
+    int has_pred_original_sample;  /* out */
+    int has_derivative;            /* out */
+} sde_step_output;
+sde_status sde_scheduler_step_output(sde_scheduler* s, const float* model_output, float timestep, const float* sample,
+                                     const float* noise, size_t n, sde_step_output* out);
 
 /* txt2img (StableDiffusionTxt2ImgOptions::run, impl_txt2img.rs:246-327) --------------------- */
 typedef enum sde_callback_kind {  /* StableDiffusionCallback, pipelines/stable_diffusion/mod.rs:41-86 */
@@ -236,6 +254,8 @@ void sde_txt2img_opts_default(sde_txt2img_opts* o);
 typedef struct sde_run_stats {
     int unet_calls; float total_ms, unet_ms, vae_ms;   /* HIP-event times on the engine's stream */
     float host_enqueue_ms;   /* host wall time spent enqueueing the UNet calls (no waiting): << unet_ms means the loop is not launch-bound */
+    int unet_graph_launches; /* UNet calls that went out as one hipGraph launch (the first call of a run, profiled passes and an engine whose
+                              * capture failed go out launch by launch: a failed capture is not an error, the run completes on plain launches) */
 } sde_run_stats;
 
 /* Runs the whole loop on the device; `scheduler` is left in the post-run state the reference
@@ -274,19 +294,23 @@ sde_status sde_synchronize(sde_engine* e);
 /* Kernel-level test hooks: run ONE contraction through the MFMA path (naive=0) or the plain path
  * (naive=1; 2 / 3 force the 256x320 / 256x160 kernels, 4 / 5 the 128x160 linear / halo 3x3 kernels) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
  * upsample: 0 none, 1 nearest 2x before the conv, 2 nearest to (2*Hi-1) x (2*Wi-1) (the exported UNet's upsample to its skip
- * connection's size on odd latents). */
+ * connection's size on odd latents), 3 = no upsample but the VAE encoder's downsampler window (pad (0,1,0,1), 3x3, stride 2, pad 0:
+ * Ho = (Hi - 2) / 2 + 1).
+ * out_capacity: the number of floats `out` holds.  The hook computes the output shape itself ([NB,Ho,Wo,Cout] resp. [NB,Sq,heads*d])
+ * and refuses (SDE_ERR_INVALID_ARGUMENT, before anything is copied) unless that is exactly out_capacity -- a caller whose shape
+ * arithmetic disagrees with the library's gets an error, never a write past its buffer. */
 sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin,
                          const float* w, const float* bias, int Cout, int ksize, int stride, int upsample,
-                         float* out);
+                         float* out, size_t out_capacity);
 /* As sde_test_conv (stride 1, no upsample; naive also takes 4 / 5 = the 128x160 linear kernel / the halo 3x3 kernel) with a
  * residual added in the epilogue: residual NHWC f32 [NB,Hi,Wi,Cout].  split = 0: residual and result are plain fp16 tensors.
  * split = 1: the residual goes in as a split-fp16 pair (hi + lo) and the result comes back as one (out = hi + lo), the form the
  * UNet trunk uses (GemmArgs::Rlo / Dlo).  Test infrastructure; no counterpart in the reference. */
 sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin,
                              const float* w, const float* bias, int Cout, int ksize, const float* residual, int split,
-                             float* out);
+                             float* out, size_t out_capacity);
 sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const float* k, const float* v,
-                              int NB, int heads, int Sq, int Skv, int d, float* out);
+                              int NB, int heads, int Sq, int Skv, int d, float* out, size_t out_capacity);
 
 #ifdef __cplusplus
 }

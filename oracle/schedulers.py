@@ -142,6 +142,8 @@ class LinearInterpolatorAccelerated:
 class _Base:
     kind = "?"
     prediction_type = "epsilon"
+    # the Option<> fields of SchedulerStepOutput (mod.rs:109-150) the last `step` filled; DPM-Solver fills none (:379)
+    last_step = dict(pred_original_sample=None, derivative=None)
 
     def order(self) -> int:
         return 1
@@ -213,6 +215,7 @@ class EulerDiscrete(_Base):
         pred = (sample - sigma_hat * model_output).astype(np.float32)
         deriv = ((sample - pred) / sigma_hat).astype(np.float32)
         dt = f32(self.sigmas[i + 1] - sigma_hat)
+        self.last_step = dict(pred_original_sample=pred, derivative=deriv)   # :216-220 returns Some(pred_original_sample)
         return (sample + deriv * dt).astype(np.float32)
 
     def add_noise(self, x0, noise, t):
@@ -241,6 +244,7 @@ class EulerAncestralDiscrete(EulerDiscrete):
         deriv = ((sample - pred) / sf).astype(np.float32)
         dt = f32(sigma_down - sf)
         prev = (sample + deriv * dt).astype(np.float32)
+        self.last_step = dict(pred_original_sample=pred, derivative=deriv)   # :206-210
         return (prev + noise.astype(np.float32) * sigma_up).astype(np.float32)
 
 
@@ -437,6 +441,7 @@ class DDIM(_Base):
             x0 = np.clip(x0, -1.0, 1.0).astype(np.float32)
         std_dev_t = f32(0.0)
         dirc = (np.sqrt(f32(f32(f32(1.0) - a_prev) - f32(std_dev_t * std_dev_t))) * mo).astype(np.float32)
+        self.last_step = dict(pred_original_sample=x0, derivative=None)      # :246-250
         return (np.sqrt(a_prev) * x0 + dirc).astype(np.float32)
 
     def add_noise(self, x0, noise, t):
@@ -509,6 +514,7 @@ class DDPM(_Base):
         c0 = f32(f32(np.sqrt(a_prev) * self.betas[pos]) / b_t)
         c1 = f32(f32(np.sqrt(self.alphas[pos]) * b_prev) / b_t)
         prev = (c0 * x0 + c1 * sample).astype(np.float32)
+        self.last_step = dict(pred_original_sample=x0, derivative=None)      # :234-238
         if pos > 0:
             v = self.get_variance(pos)
             if self.variance_type != "fixed_small_log":
@@ -561,6 +567,7 @@ class LMSDiscrete(EulerDiscrete):
         sigma = self.sigmas[i]
         pred = (sample - sigma * model_output).astype(np.float32)
         deriv = ((sample - pred) / sigma).astype(np.float32)
+        self.last_step = dict(pred_original_sample=pred, derivative=deriv)
         self.derivatives.append(deriv)
         if len(self.derivatives) > self.ORDER:
             self.derivatives.pop(0)

@@ -62,7 +62,10 @@ pub struct sde_txt2img_opts { pub height: c_int, pub width: c_int, pub guidance_
     pub start_step: c_int }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
-pub struct sde_run_stats { pub unet_calls: c_int, pub total_ms: c_float, pub unet_ms: c_float, pub vae_ms: c_float, pub host_enqueue_ms: c_float }
+pub struct sde_run_stats { pub unet_calls: c_int, pub total_ms: c_float, pub unet_ms: c_float, pub vae_ms: c_float, pub host_enqueue_ms: c_float, pub unet_graph_launches: c_int }
+
+#[repr(C)] #[derive(Clone, Copy)]
+pub struct sde_step_output { pub prev_sample: *mut c_float, pub pred_original_sample: *mut c_float, pub derivative: *mut c_float, pub has_pred_original_sample: c_int, pub has_derivative: c_int }
 
 #[repr(C)] #[derive(Clone, Copy)]
 pub struct sde_kernel_stat { pub name: [c_char; 48], pub launches: u64, pub total_ms: c_double, pub flops: c_double, pub bytes: c_double }
@@ -77,7 +80,7 @@ extern "C" {
     pub fn sde_engine_destroy(e: *mut sde_engine);
     pub fn sde_engine_info(e: *const sde_engine, info: *mut sde_model_info) -> c_int;
     pub fn sde_unet_forward(e: *mut sde_engine, sample: *const c_float, n: c_int, h: c_int, w: c_int, timestep: c_float,
-                            ehs: *const c_float, s: c_int, d: c_int, out: *mut c_float) -> c_int;
+                            ehs: *const c_float, s: c_int, d: c_int, out: *mut c_float, out_capacity: usize) -> c_int;
     pub fn sde_unet_forward_dev(e: *mut sde_engine, d_sample: *const c_float, n: c_int, h: c_int, w: c_int, timestep: c_float,
                                 d_ehs: *const c_float, s: c_int, d: c_int, d_out: *mut c_float) -> c_int;
     pub fn sde_vae_decode(e: *mut sde_engine, latents: *const c_float, b: c_int, h: c_int, w: c_int, images: *mut c_float) -> c_int;
@@ -106,6 +109,8 @@ extern "C" {
                               noise: *const c_float, n: usize, prev_sample: *mut c_float) -> c_int;
     pub fn sde_scheduler_add_noise(s: *mut sde_scheduler, original: *const c_float, noise: *const c_float, n: usize,
                                    timestep: c_float, out: *mut c_float) -> c_int;
+    pub fn sde_scheduler_step_output(s: *mut sde_scheduler, model_output: *const c_float, timestep: c_float, sample: *const c_float,
+                                     noise: *const c_float, n: usize, out: *mut sde_step_output) -> c_int;
     pub fn sde_txt2img_opts_default(o: *mut sde_txt2img_opts);
     pub fn sde_txt2img_run(e: *mut sde_engine, s: *mut sde_scheduler, o: *const sde_txt2img_opts,
                            images: *mut c_float, stats: *mut sde_run_stats) -> c_int;
@@ -118,10 +123,10 @@ extern "C" {
     pub fn sde_synchronize(e: *mut sde_engine) -> c_int;
     pub fn sde_test_conv(e: *mut sde_engine, naive: c_int, x: *const c_float, nb: c_int, hi: c_int, wi: c_int, cin: c_int,
                          w: *const c_float, bias: *const c_float, cout: c_int, ksize: c_int, stride: c_int, upsample: c_int,
-                         out: *mut c_float) -> c_int;
+                         out: *mut c_float, out_capacity: usize) -> c_int;
     pub fn sde_test_conv_res(e: *mut sde_engine, naive: c_int, x: *const c_float, nb: c_int, hi: c_int, wi: c_int, cin: c_int,
                              w: *const c_float, bias: *const c_float, cout: c_int, ksize: c_int, residual: *const c_float, split: c_int,
-                             out: *mut c_float) -> c_int;
+                             out: *mut c_float, out_capacity: usize) -> c_int;
     pub fn sde_test_attention(e: *mut sde_engine, naive: c_int, q: *const c_float, k: *const c_float, v: *const c_float,
-                              nb: c_int, heads: c_int, sq: c_int, skv: c_int, d: c_int, out: *mut c_float) -> c_int;
+                              nb: c_int, heads: c_int, sq: c_int, skv: c_int, d: c_int, out: *mut c_float, out_capacity: usize) -> c_int;
 }

@@ -31,7 +31,7 @@ def run_conv(engine, naive, x, w, b, k, stride, ups):
     Ho, Wo = ((Hv - 1) // stride + 1, (Wv - 1) // stride + 1) if k == 3 else (Hv, Wv)
     out = np.empty((NB, Ho, Wo, Cout), np.float32)
     _lib.check(_lib.lib().sde_test_conv(engine._h, naive, x.ctypes.data, NB, Hi, Wi, Cin, w.ctypes.data,
-                                        b.ctypes.data if b is not None else None, Cout, k, stride, int(ups), out.ctypes.data))
+                                        b.ctypes.data if b is not None else None, Cout, k, stride, int(ups), out.ctypes.data, out.size))
     return out
 
 
@@ -180,7 +180,7 @@ def test_conv_residual_epilogue(engine, case, split):
     res = (rng.standard_normal((NB, H, W, Cout)) * 3).astype(np.float32)
     out = np.empty((NB, H, W, Cout), np.float32)
     _lib.check(_lib.lib().sde_test_conv_res(engine._h, kern, x.ctypes.data, NB, H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, k,
-                                            res.ctypes.data, split, out.ctypes.data))
+                                            res.ctypes.data, split, out.ctypes.data, out.size))
     xt = torch.from_numpy(x).half().double().permute(0, 3, 1, 2)
     conv = F.conv2d(xt, torch.from_numpy(w).half().double(), torch.from_numpy(b).double(), stride=1, padding=k // 2).permute(0, 2, 3, 1).numpy()
     if split:
@@ -266,7 +266,7 @@ def run_attn(engine, naive, q, k, v, heads):
     Skv = k.shape[1]
     out = np.empty_like(q)
     _lib.check(_lib.lib().sde_test_attention(engine._h, naive, q.ctypes.data, k.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv,
-                                             Cc // heads, out.ctypes.data))
+                                             Cc // heads, out.ctypes.data, out.size))
     return out
 
 
@@ -316,3 +316,25 @@ def test_attention_softmax_rescale_branch(engine):
     qt, kt, vt = (torch.from_numpy(t).half().double() for t in (q, k, v))
     ref = (torch.softmax(qt @ kt.transpose(-1, -2) * d ** -0.5, dim=-1) @ vt).numpy()
     assert np.abs(fast - ref).max() < 2e-2 and rel_l2(fast, ref) < 3e-3
+
+
+def test_hooks_refuse_a_buffer_of_the_wrong_size(engine):
+    """The hooks compute their own output shape; a caller whose arithmetic disagrees (here: the symmetric-padding formula
+    (H - 1) // 2 + 1 for the asymmetric-padding window on odd sizes, 8 x 5 instead of 7 x 4 rows) is refused before any
+    copy -- the class of host heap overrun behind round 2's segfault in a GPU-test process."""
+    from diffusers_amd import _lib
+    L = _lib.lib()
+    NB, H, W, Cin, Cout = 1, 15, 9, 64, 64
+    x = np.zeros((NB, H, W, Cin), np.float32)
+    w = np.zeros((Cout, Cin, 3, 3), np.float32)
+    guard = np.full(8 * 5 * Cout + 64, 7.0, np.float32)
+    for cap in (8 * 5 * Cout, 7 * 4 * Cout - 1, 0):
+        st = L.sde_test_conv(engine._h, 0, x.ctypes.data, NB, H, W, Cin, w.ctypes.data, None, Cout, 3, 2, 3, guard.ctypes.data, cap)
+        assert st == 1 and b"out_capacity" in L.sde_last_error()
+    assert (guard == 7.0).all()
+    st = L.sde_test_conv_res(engine._h, 0, x.ctypes.data, NB, H, W, Cin, w.ctypes.data, None, Cout, 3, guard.ctypes.data, 0, guard.ctypes.data, 5)
+    assert st == 1 and b"out_capacity" in L.sde_last_error()
+    q = np.zeros((1, 64, 64), np.float32)
+    st = L.sde_test_attention(engine._h, 0, q.ctypes.data, q.ctypes.data, q.ctypes.data, 1, 4, 64, 64, 16, guard.ctypes.data, 64 * 64 + 1)
+    assert st == 1 and b"out_capacity" in L.sde_last_error()
+    assert (guard == 7.0).all()

@@ -187,10 +187,13 @@ def test_txt2img_size_check_and_callbacks(pipe):
     bad = StableDiffusionTxt2ImgOptions(height=100, width=128, text_embeddings=ehs, batch_size=1, steps=2)
     with pytest.raises(_lib.SdeError, match="divisible by 8"):
         bad.run(pipe, sch, skip_decode=True)
-    # an empty schedule (DDIM, one inference step: ddim.rs:184 yields n - 1 timesteps) is refused, not decoded as noise (sdengine.h)
-    one = StableDiffusionTxt2ImgOptions(height=128, width=128, text_embeddings=ehs, batch_size=1, steps=1, seed=1)
-    with pytest.raises(_lib.SdeError, match="no timesteps"):
-        one.run(pipe, N.BY_NAME["ddim"].stable_diffusion_v1_optimized_default(), skip_decode=True)
+    # an empty schedule (DDIM, one inference step: ddim.rs:184 yields n - 1 timesteps): the reference runs no step and decodes
+    # init_noise_sigma * latents (impl_txt2img.rs:265,272,326), and so does the engine in parity mode; with the quirks off it is refused
+    init = np.random.default_rng(9).standard_normal((1, 4, 16, 16)).astype(np.float32)
+    one = StableDiffusionTxt2ImgOptions(height=128, width=128, text_embeddings=ehs, batch_size=1, steps=1, init_latents=init)
+    r = one.run(pipe, N.BY_NAME["ddim"].stable_diffusion_v1_optimized_default(), trace=True)
+    assert r.unet_calls == 0 and np.array_equal(r.final_latents, init)            # DDIM: init_noise_sigma = 1
+    assert np.array_equal(r.images, pipe.decode_latents(init))
     seen = []
     o = StableDiffusionTxt2ImgOptions(height=128, width=128, text_embeddings=ehs, batch_size=1, steps=6, seed=1)
     o.callback_progress(2, lambda i, t: (seen.append(i) or True) and i < 2)   # stop after step 2
@@ -457,3 +460,27 @@ def test_cfg_pair_split_matches_single_engine(tiny_model_dir, pipe, kind, rescal
     o.text_embeddings = ehs[:B]
     with pytest.raises(_lib.SdeError, match="cfg_half"):
         o.run(pipe, N.BY_NAME[kind].stable_diffusion_v1_optimized_default(), cfg_pair=ThreadPair(0))
+
+
+def test_failed_graph_capture_falls_back_to_plain_launches(pipe, tiny_model_dir, monkeypatch):
+    """A UNet call is captured into a hipGraph on its second use.  If anything throws while the stream is capturing, the engine
+    ends the capture, turns graphs off and replays the call launch by launch: the run completes with identical results
+    (fault injected with SDE_TEST_CAPTURE_FAULT, read at engine creation)."""
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionPipeline, StableDiffusionTxt2ImgOptions
+    rng = np.random.default_rng(77)
+    ehs = (rng.standard_normal((2, 77, 64)) * 0.5).astype(np.float32)
+    init = rng.standard_normal((1, 4, 16, 16)).astype(np.float32)
+    opts = StableDiffusionTxt2ImgOptions(height=128, width=128, steps=4, text_embeddings=ehs, batch_size=1, init_latents=init)
+    good = opts.run(pipe, N.DPMSolverMultistepScheduler.stable_diffusion_v1_optimized_default(), trace=True)
+    assert good.unet_calls == 4 and good.unet_graph_launches == 3       # the first call of a run fills the text K/V cache, uncaptured
+    monkeypatch.setenv("SDE_TEST_CAPTURE_FAULT", "1")
+    p2 = StableDiffusionPipeline(tiny_model_dir)
+    monkeypatch.delenv("SDE_TEST_CAPTURE_FAULT")
+    try:
+        for _ in range(2):                                                # the second run must not try (and fail) again
+            r = opts.run(p2, N.DPMSolverMultistepScheduler.stable_diffusion_v1_optimized_default(), trace=True)
+            assert r.unet_calls == 4 and r.unet_graph_launches == 0
+            assert np.array_equal(r.noise_pred, good.noise_pred) and np.array_equal(r.images, good.images)
+    finally:
+        p2.close()

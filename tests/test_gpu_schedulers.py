@@ -143,3 +143,35 @@ def test_add_noise():
         s = N.BY_NAME[kind].stable_diffusion_v1_optimized_default(); s.set_timesteps(20)
         t = o.timesteps[5]
         assert np.abs(s.add_noise(x, nz, float(t)) - o.add_noise(x, nz, t)).max() < 1e-5
+
+
+@pytest.mark.parametrize("kind,pred", [("euler", None), ("euler_a", None), ("lms", None), ("ddim", "epsilon"), ("ddim", "v_prediction"),
+                                       ("ddpm", "epsilon"), ("dpmpp", "epsilon")])
+def test_step_output_optional_fields(kind, pred):
+    """SchedulerStepOutput (schedulers/mod.rs:109-150): `pred_original_sample` where the reference's step returns Some(..)
+    (Euler / Euler-a / DDIM / DDPM), None for DPM-Solver (dpm_solver_multistep.rs:379); the Euler family's derivative on request."""
+    from diffusers_amd import schedulers as N
+    from oracle import schedulers as S
+    rng = np.random.default_rng(21)
+    kw = {} if pred is None else dict(prediction_type=pred)
+    o = S.make(kind, **kw); o.set_timesteps(12)
+    s = N.BY_NAME[kind].stable_diffusion_v1_optimized_default(**kw); s.set_timesteps(12)
+    x = xo = (rng.standard_normal((1, 4, 8, 8)).astype(np.float32) * o.init_noise_sigma()).astype(np.float32)
+    for t in o.timesteps[:5]:
+        e = rng.standard_normal(x.shape).astype(np.float32)
+        nz = rng.standard_normal(x.shape).astype(np.float32)
+        s.scale_model_input(x, float(t)); o.scale_model_input(xo, t)
+        out = s.step_output(e, float(t), x, nz)
+        xo = o.step(e, t, xo, nz)
+        x = out.prev_sample()
+        assert np.abs(x - xo).max() <= 1e-5 * max(1.0, np.abs(xo).max())
+        assert out.prev_sample_mean() is None
+        want = o.last_step
+        if want["pred_original_sample"] is None:
+            assert out.pred_original_sample() is None and kind == "dpmpp"
+        else:
+            assert np.abs(out.pred_original_sample() - want["pred_original_sample"]).max() <= 1e-5 * max(1.0, np.abs(want["pred_original_sample"]).max())
+        if want["derivative"] is None:
+            assert out.derivative() is None
+        else:
+            assert np.abs(out.derivative() - want["derivative"]).max() <= 1e-5 * max(1.0, np.abs(want["derivative"]).max())

@@ -106,9 +106,8 @@ def test_asymmetric_pad_stride2_conv(model_dir_enc, case, kern):
         b = rng.standard_normal(Cout).astype(np.float32)
         Ho, Wo = (H - 2) // 2 + 1, (W - 2) // 2 + 1
         out = np.empty((NB, Ho, Wo, Cout), np.float32)
-        _lib.check(_lib.lib().sde_test_conv(pipe._h, kern, x.ctypes.data, NB, H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, 3, 2, 3, out.ctypes.data))
-        xt = torch.zeros(NB, Cin, H + 1, W + 1)      # F.pad(x, (0, 1, 0, 1)), written out (this torch build's pad crashes on a permuted view)
-        xt[:, :, :H, :W] = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
+        _lib.check(_lib.lib().sde_test_conv(pipe._h, kern, x.ctypes.data, NB, H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, 3, 2, 3, out.ctypes.data, out.size))
+        xt = F.pad(torch.from_numpy(x).half().float().permute(0, 3, 1, 2), (0, 1, 0, 1))
         ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=2, padding=0).permute(0, 2, 3, 1).numpy()
         assert out.shape == ref.shape
         assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
@@ -170,5 +169,30 @@ def test_img2img_loop_start(model_dir_enc, kind, strength):
         bad.init_latents, bad.start_step = noised, 1000
         with pytest.raises(Exception, match="start_step"):
             bad.run(pipe, sched)
+    finally:
+        pipe.close()
+
+
+def test_img2img_ddim_last_slot_is_empty(model_dir_enc):
+    """The reference's DDIM yields steps - 1 timesteps (ddim.rs:184): a strength with int(steps * strength) == 1 gives
+    t_start == steps - 1 == len(timesteps), an empty slice -- no UNet call, the encoded image is decoded un-noised (pipeline.py)."""
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionImg2ImgOptions, StableDiffusionPipeline
+    pipe = StableDiffusionPipeline(model_dir_enc).load_vae_encoder()
+    try:
+        B, H, W, steps = 1, 64, 48, 8
+        rng = np.random.default_rng(3)
+        img = rng.uniform(0, 1, (B, H // 4, W // 4, 3)).astype(np.float32)
+        ehs = (rng.standard_normal((2 * B, 77, 64)) * 0.5).astype(np.float32)
+        opts = (StableDiffusionImg2ImgOptions().with_size(W, H).with_steps(steps).with_noise_strength(0.2).with_seed(5)
+                .with_text_embeddings(ehs, B).with_images(img))
+        sched = N.DDIMScheduler.stable_diffusion_v1_optimized_default()
+        sched.set_timesteps(steps)
+        assert opts.start_step() == steps - 1 == len(sched.timesteps())
+        res = opts.run(pipe, sched)
+        assert res.unet_calls == 0 and res.images.shape == (B, H // 4, W // 4, 3)
+        # Euler at the same strength has a slot left: one UNet call
+        res2 = opts.run(pipe, N.EulerDiscreteScheduler.stable_diffusion_v1_optimized_default())
+        assert res2.unet_calls == 1
     finally:
         pipe.close()

@@ -53,7 +53,7 @@ def main():
             Ho, Wo = ((Hv - 1) // stride + 1, (Wv - 1) // stride + 1) if k == 3 else (Hv, Wv)
             out = np.empty((NB, Ho, Wo, cout), np.float32)
             _lib.check(L.sde_test_conv(pipe._h, kern, x.ctypes.data, NB, H, W, cin, w.ctypes.data, b.ctypes.data, cout, k, stride, ups,
-                                       out.ctypes.data))
+                                       out.ctypes.data, out.size))
             xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
             if ups:
                 xt = F.interpolate(xt, size=(Hv, Wv), mode="nearest")
@@ -71,7 +71,7 @@ def main():
             kk = rng.standard_normal((NB, Skv, heads * dd)).astype(np.float32)
             v = rng.standard_normal((NB, Skv, heads * dd)).astype(np.float32)
             out = np.empty_like(q)
-            _lib.check(L.sde_test_attention(pipe._h, kern, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data))
+            _lib.check(L.sde_test_attention(pipe._h, kern, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
             sp = lambda t, S: torch.from_numpy(t).half().float().reshape(NB, S, heads, dd).permute(0, 2, 1, 3)
             ref = F.scaled_dot_product_attention(sp(q, Sq), sp(kk, Skv), sp(v, Skv)).permute(0, 2, 1, 3).reshape(NB, Sq, heads * dd).numpy()
             err, tag = rel_l2(out, ref), f"attn kern={kern} NB={NB} heads={heads} Sq={Sq} Skv={Skv} d={dd}"

@@ -61,14 +61,7 @@ def main():
             ref_img = unet_ref.decode_latents(vw, vc, torch.from_numpy(ref["final"])).numpy()
         opts = StableDiffusionTxt2ImgOptions(height=h * 8, width=w * 8, guidance_scale=guidance, rescale_cfg=rescale, steps=steps, text_embeddings=ehs,
                                              batch_size=B, init_latents=init, step_noise=noise)
-        if len(ref["timesteps"]) == 0:     # DDIM, one step: n - 1 = 0 timesteps (ddim.rs:184); the engine refuses an empty schedule (sdengine.h)
-            try:
-                opts.run(pipe, N.BY_NAME[kind].stable_diffusion_v1_optimized_default(), trace=True)
-                print(f"MISS {kind:8s} steps={steps}: an empty schedule was not refused", flush=True); bad += 1
-            except Exception as e:
-                assert "no timesteps" in str(e), e
-                print(f"ok   {kind:8s} steps={steps}: empty schedule refused", flush=True)
-            continue
+        # an empty schedule (DDIM, one step: n - 1 = 0 timesteps, ddim.rs:184) runs no UNet call and decodes the scaled initial latents, as the reference does
         res = opts.run(pipe, N.BY_NAME[kind].stable_diffusion_v1_optimized_default(), trace=True)
         errs = [rel_l2(res.noise_pred[i], ref["noise_pred"][i]) for i in range(res.unet_calls)] or [0.0]   # an empty schedule (DDIM, 1 step) runs no UNet call
         p = psnr(res.images, ref_img)

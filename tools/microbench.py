@@ -41,10 +41,10 @@ def main():
         Hv = 2 * H if ups else H
         Ho = (Hv - 1) // stride + 1 if k == 3 else Hv
         out = np.empty((NB, Ho, Ho, Cout), np.float32)
-        _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
+        _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data, out.size))
         p.profile_reset(); p.profile(True)
         for _ in range(reps):
-            _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data))
+            _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data, out.size))
         st = [s for s in p.profile_get() if "mfma" in s["name"]]
         p.profile(False)
         for s in st:
@@ -55,10 +55,10 @@ def main():
         kk = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
         v = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
         out = np.empty_like(q)
-        _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data))
+        _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
         p.profile_reset(); p.profile(True)
         for _ in range(reps):
-            _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data))
+            _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
         st = [s for s in p.profile_get() if "attn" in s["name"]]
         p.profile(False)
         for s in st:
