@@ -208,6 +208,44 @@ def test_config3_euler_a_batch8_two_steps(sd15):
     _loop_at_config_batch(pipe, uw, ucfg, vw, vcfg, "euler_a", 8, 77, 768, 64, 64, 2, 7.5)
 
 
+def test_config2_dpmpp_batch8_two_steps(sd15):
+    """BASELINE configs[1], the benchmarked configuration itself: DPM++ (reference quirk: first order), B = 8 (UNet batch 16),
+    S = 77, CFG 7.5, 512x512 + batched decode (impl_txt2img.rs:272-304)."""
+    pipe, uw, ucfg, vw, vcfg = sd15
+    _loop_at_config_batch(pipe, uw, ucfg, vw, vcfg, "dpmpp", 8, 77, 768, 64, 64, 2, 7.5)
+
+
+def test_config1_euler_fp32_engine_three_steps():
+    """BASELINE configs[0]'s arithmetic on the GPU: SD v1.5 geometry, fp32 engine, Euler, B = 1 under CFG 7.5 -- three steps of the
+    loop against the oracle at the fp32 bar (1e-4 per step on the CFG-combined noise prediction, north_star)."""
+    from diffusers_amd import schedulers as N
+    from diffusers_amd.pipeline import StableDiffusionOptions, StableDiffusionPipeline, StableDiffusionTxt2ImgOptions
+    from oracle import model_dir, schedulers as S, txt2img as T, unet_ref
+    assert os.path.exists(os.path.join(MODEL_DIR, ".complete"))      # written by the module fixture of the tests above
+    pipe = StableDiffusionPipeline(MODEL_DIR, StableDiffusionOptions(dtype="f32"), load_vae=False)
+    try:
+        uw, ucfg = model_dir.load_unet(MODEL_DIR)
+        uw = {k: torch.from_numpy(v) for k, v in uw.items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        rng = np.random.default_rng(101)
+        ehs = (rng.standard_normal((2, 77, 768)) * 0.5).astype(np.float32)
+        init = rng.standard_normal((1, 4, 64, 64)).astype(np.float32)
+        unet = lambda x, t, e: unet_ref.unet_forward(uw, ucfg, torch.from_numpy(x), t, torch.from_numpy(e)).numpy()
+        with torch.no_grad():
+            ref = T.run(unet, S.make("euler"), ehs, init, 3, 7.5)
+        opts = StableDiffusionTxt2ImgOptions(height=512, width=512, steps=3, text_embeddings=ehs, batch_size=1, init_latents=init)
+        res = opts.run(pipe, N.EulerDiscreteScheduler.stable_diffusion_v1_optimized_default(), trace=True, skip_decode=True)
+        errs = [rel_l2(res.noise_pred[i], ref["noise_pred"][i]) for i in range(3)]
+        if os.environ.get("SDE_PARITY_LOG"):
+            with open(os.environ["SDE_PARITY_LOG"], "a") as f:
+                f.write("f32 engine config1 euler B=1: " + " ".join(f"step{i}={e:.3e}" for i, e in enumerate(errs)) +
+                        f" latents={rel_l2(res.final_latents, ref['final']):.3e} unet_ms={res.unet_ms:.0f}\n")
+        assert max(errs) < 1e-4, errs
+        assert rel_l2(res.final_latents, ref["final"]) < 1e-4
+    finally:
+        pipe.close()
+
+
 def test_config5_lms_batch16_long_prompt_two_steps(sd15):
     """BASELINE configs[4]: LMS, B = 16 (UNet batch 32), 227-token weighted prompts, + 16 VAE decodes."""
     pipe, uw, ucfg, vw, vcfg = sd15
