@@ -114,6 +114,7 @@ SYMBOLS = {
     "sde_synchronize": (_i, [_vp]),
     "sde_test_conv": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, C.c_size_t]),
     "sde_test_conv_res": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp, C.c_size_t]),
+    "sde_test_geglu": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _i, _vp, C.c_size_t]),
     "sde_test_attention": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t]),
 }
 

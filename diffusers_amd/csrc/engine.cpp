@@ -1173,7 +1173,7 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         SDE_REQUIRE(NB > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && stride >= 1 && stride <= 2, SDE_ERR_INVALID_ARGUMENT, "bad conv geometry");
         EngineLock lk(e);
         engine_activate(e);
-        LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3; ctx.force_mid128 = naive == 4; ctx.force_midh = naive == 5;   // 0 fast, 1 plain, 2 / 3 / 4 / 5 force the 256x320 / 256x160 / 128x160 / halo kernel
+        LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3; ctx.force_mid128 = naive == 4; ctx.force_midh = naive == 5; ctx.force_ws = naive == 6;   // 0 fast, 1 plain, 2 / 3 / 4 / 5 / 6 force the 256x320 / 256x160 / 128x160 / halo / W-stationary kernel
         const int taps = ksize * ksize;
         // upsample: 1 = nearest 2x; 2 = 2x cropped to (2*Hi - 1) x (2*Wi - 1), the UNet's upsample-to-skip-size on odd latents
         // upsample == 3: not an upsample -- the VAE encoder's downsampler, pad (0,1,0,1) + a pad-0 stride-2 window (GemmArgs::coff = 1)
@@ -1223,6 +1223,7 @@ sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, i
         engine_activate(e);
         LaunchCtx ctx = e->ctx; ctx.f32 = false;
         ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_mid = naive == 3; ctx.force_mid128 = naive == 4; ctx.force_midh = naive == 5;
+        ctx.force_ws = naive == 6;
         const int taps = ksize * ksize;
         const size_t nx = (size_t)NB * Hi * Wi * Cin, nw = (size_t)Cout * Cin * taps, no = (size_t)NB * Hi * Wi * Cout;
         const int Npad = gemm_npad(Cout), K = taps * Cin;
@@ -1255,6 +1256,42 @@ sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, i
         HIP_CHECK(hipMemcpy(rhi.data(), doh.p, no * 2, hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(rlo.data(), dol.p, no * 2, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < no; ++i) out[i] = (float)rhi[i] + (split ? (float)rlo[i] : 0.f);
+    });
+}
+
+sde_status sde_test_geglu(sde_engine* e, int naive, const float* x, int M, int K, const float* w, const float* bias, int N, int gelu_tanh,
+                          float* out, size_t out_capacity)
+{
+    return guarded([&] {
+        SDE_REQUIRE(e && x && w && out, SDE_ERR_INVALID_ARGUMENT, "null argument");
+        SDE_REQUIRE(M > 0 && K > 0 && N > 0 && (N / 2) % 16 == 0 && N % 2 == 0, SDE_ERR_INVALID_ARGUMENT, "GEGLU projection width must be a multiple of 32");
+        require_out_capacity("sde_test_geglu", (size_t)M * (N / 2), out_capacity, "[" + std::to_string(M) + "," + std::to_string(N / 2) + "]");
+        EngineLock lk(e);
+        engine_activate(e);
+        LaunchCtx ctx = e->ctx; ctx.f32 = false;
+        ctx.force_naive = naive == 1; ctx.force_big = naive == 2; ctx.force_ws = naive == 6;
+        const bool pair = N % 320 == 0 && K % 64 == 0;      // the loader's rule (WeightBuilder::linear)
+        const size_t nx = (size_t)M * K, nw = (size_t)N * K, no = (size_t)M * (N / 2);
+        const int Npad = gemm_npad(N);
+        DevBuf dxf, dxh, dwf, dwh, dbias, doh, dof;
+        dxf.ensure(nx * 4); dxh.ensure(nx * 2); dwf.ensure(nw * 4); dwh.ensure((size_t)Npad * K * 2); doh.ensure(no * 2); dof.ensure(no * 4);
+        HIP_CHECK(hipMemcpy(dxf.p, x, nx * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(dwf.p, w, nw * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemsetAsync(dwh.p, 0, (size_t)Npad * K * 2, e->stream));
+        if (bias) { dbias.ensure((size_t)N * 4); HIP_CHECK(hipMemcpy(dbias.p, bias, (size_t)N * 4, hipMemcpyHostToDevice)); }
+        launch_f32_to_f16(ctx, dxf.as<float>(), dxh.as<half_t>(), (int64_t)nx);
+        RepackArgs r;
+        r.src = dwf.p; r.src_is_f16 = 0; r.O = N; r.I = K; r.KH = 1; r.KW = 1; r.in_out = 0; r.dst = dwh.as<half_t>();
+        r.dst_row0 = 0; r.Ipad = K; r.i0 = 0; r.Kdst = K; r.geglu_half = N / 2; r.geglu_pair = pair ? 1 : 0;
+        launch_repack(ctx, r);
+        GemmArgs g;
+        g.A0 = dxh.as<half_t>(); g.lda0 = K; g.C0 = K; g.taps = 1; g.M = M; g.N = N; g.K = K;
+        g.W = dwh.as<half_t>(); g.Npad = Npad; g.bias = bias ? dbias.as<float>() : nullptr; g.D = doh.as<half_t>(); g.ldd = N / 2;
+        g.epi = pair ? EPI_GEGLU_PAIR : EPI_GEGLU; g.gelu_tanh = gelu_tanh ? 1 : 0;
+        launch_gemm(ctx, g);
+        launch_f16_to_f32(ctx, doh.as<half_t>(), dof.as<float>(), (int64_t)no);
+        HIP_CHECK(hipStreamSynchronize(e->stream));
+        HIP_CHECK(hipMemcpy(out, dof.p, no * 4, hipMemcpyDeviceToHost));
     });
 }
 

@@ -272,6 +272,8 @@ void launch_gemm_mid(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 void launch_gemm_mid128(const LaunchCtx& ctx, GemmDev& p, int batch);
 bool gemm_midh_supported(const GemmArgs& a);
 void launch_gemm_midh(const LaunchCtx& ctx, GemmDev& p);
+bool gemm_ws_supported(const GemmArgs& a);
+void launch_gemm_ws(const LaunchCtx& ctx, GemmDev& p);
 void launch_gemm_big(const LaunchCtx& ctx, GemmDev& p, int batch, bool conv);
 
 int gemm_npad(int N) { return (N % 160 == 0 || N % 128 == 0) ? N : round_up(N, 128); }
@@ -285,7 +287,7 @@ static GemmDev to_dev(const LaunchCtx& ctx, const GemmArgs& a)
     p.Hs = a.ups ? (a.Hi + 1) / 2 : a.Hi; p.Ws = a.ups ? (a.Wi + 1) / 2 : a.Wi;   // ups: virtual (Hi x Wi) = nearest-2x of (Hs x Ws), cropped when odd
     p.W = a.W; p.Npad = a.Npad; p.bias = a.bias; p.R = a.R; p.Rlo = a.Rlo; p.Dlo = a.Dlo; p.ldr = a.ldr; p.D = a.D; p.Df = a.Df; p.ldd = a.ldd;
     p.epi = a.epi; p.gelu_tanh = a.gelu_tanh; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR; p.zeros = ctx.zeros;
-    p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr; p.stamps = nullptr;
+    p.nbm = p.nbn = 0; p.splitk = 1; p.ws = nullptr; p.stamps = nullptr; p.ws_npp = 1;
     // fabric reads ~ A + 8*W with column tiles fastest, 8*A + W with row tiles fastest (8 XCDs, each with its own L2)
     {
         static const int cm_env = getenv("SDE_COLMAJOR") ? atoi(getenv("SDE_COLMAJOR")) : -1;   // tuning hook
@@ -390,6 +392,20 @@ void launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
         {
             ProfScope ps(ctx, prof_name("conv3x3_mfma_halo", a, "Q"), flops, bytes);
             launch_gemm_midh(ctx, p);
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    // K = 320 projections over many rows (the 64x64 UNet level): the W-stationary streaming kernel (gemm_ws.hip).  Measured against the
+    // 256x320 kernel at M = 65536 (us, HIP events): GEGLU N = 2560 150.7 / 163.8, q / k / v N = 960 66.5 / 70.8, N = 320 29.2 / 28.6 (a tie:
+    // both sit ~20 % above what a LayerNorm pass over the same 84 MB takes, and stay where they are)
+    static const int ws_env = getenv("SDE_WS") ? atoi(getenv("SDE_WS")) : 1;   // tuning hook: 0 never, 1 heuristic, 2 whenever supported
+    static const int ws_min_m = getenv("SDE_WS_MIN_M") ? atoi(getenv("SDE_WS_MIN_M")) : 16384;
+    if (!ctx.force_naive && !ctx.force_big && !ctx.force_mid && !ctx.force_mid128 && !ctx.force_midh && gemm_ws_supported(a) &&
+        (ctx.force_ws || ws_env == 2 || (ws_env && a.M >= ws_min_m && (a.epi == EPI_GEGLU_PAIR || a.Npad >= 960)))) {
+        {
+            ProfScope ps(ctx, prof_name(a.epi == EPI_GEGLU_PAIR ? "gemm_geglu_mfma_ws" : "gemm_mfma_ws", a, "W"), flops, bytes);
+            launch_gemm_ws(ctx, p);
         }
         HIP_CHECK(hipGetLastError());
         return;

@@ -23,6 +23,7 @@ struct GemmDev {
     int colmajor;            // tile order inside an XCD's contiguous chunk: 0 = column tile fastest (A panel stays in L2), 1 = row tile fastest (W panel stays in L2)
     unsigned* stamps;        // diagnostic builds (-DSDE_DIAG): per-wave section cycle sums of one block, else null
     int splitk; float* ws;   // splitk > 1: raw fp32 partial tiles go to ws[ks][M][Npad], reduced by splitk_reduce_kernel
+    int ws_npp;              // gemm_ws.hip: panels per pass
 };
 
 // exact-erf GELU, 0.5*x*(1+erf(x/sqrt2)), with erf from Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the

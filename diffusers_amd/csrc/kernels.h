@@ -19,6 +19,7 @@ struct LaunchCtx {
     bool force_mid128 = false;      // test hook: take the 128x160 loader-wave kernel (linears) whenever it supports the problem
     bool force_midh = false;        // test hook: take the halo 3x3 kernel (16 x 16 output patches) whenever it supports the problem
     bool force_big = false;         // test hook: take the 8-wave 256x320 kernel whenever it supports the problem
+    bool force_ws = false;          // test hook: take the W-stationary streaming kernel (gemm_ws.hip) whenever it supports the problem
     float* splitk_ws = nullptr;     // fp32 partial-tile workspace for split-K GEMMs (null: split-K off)
     size_t splitk_ws_bytes = 0;
     int splitk_force = 0;           // tuning hook: >0 forces this split factor where split-K applies

@@ -292,7 +292,8 @@ sde_status sde_profile_get(sde_engine* e, sde_kernel_stat* out, int capacity, in
 sde_status sde_synchronize(sde_engine* e);
 
 /* Kernel-level test hooks: run ONE contraction through the MFMA path (naive=0) or the plain path
- * (naive=1; 2 / 3 force the 256x320 / 256x160 kernels, 4 / 5 the 128x160 linear / halo 3x3 kernels) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
+ * (naive=1; 2 / 3 force the 256x320 / 256x160 kernels, 4 / 5 the 128x160 linear / halo 3x3 kernels, 6 the W-stationary streaming
+ * kernel for short-K linears, gemm_ws.hip) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
  * upsample: 0 none, 1 nearest 2x before the conv, 2 nearest to (2*Hi-1) x (2*Wi-1) (the exported UNet's upsample to its skip
  * connection's size on odd latents), 3 = no upsample but the VAE encoder's downsampler window (pad (0,1,0,1), 3x3, stride 2, pad 0:
  * Ho = (Hi - 2) / 2 + 1).
@@ -309,6 +310,12 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
 sde_status sde_test_conv_res(sde_engine* e, int naive, const float* x, int NB, int Hi, int Wi, int Cin,
                              const float* w, const float* bias, int Cout, int ksize, const float* residual, int split,
                              float* out, size_t out_capacity);
+/* The GEGLU projection (BiasSplitGelu, scripts/_optimizer/fusion_biassplitgelu.py:15-110) as one GEMM with the gate product in the
+ * epilogue: x f32 [M,K]; w f32 [N,K] with the N/2 value rows first, then the N/2 gate rows (file order); out f32 [M,N/2] =
+ * (x Wv^T + bv) * gelu(x Wg^T + bg), exact-erf GELU or (gelu_tanh = 1) FastGelu's tanh form.  naive: 0 heuristic, 1 plain, 2 the
+ * 256x320 kernel, 6 the W-stationary streaming kernel. */
+sde_status sde_test_geglu(sde_engine* e, int naive, const float* x, int M, int K, const float* w, const float* bias, int N,
+                          int gelu_tanh, float* out, size_t out_capacity);
 sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const float* k, const float* v,
                               int NB, int heads, int Sq, int Skv, int d, float* out, size_t out_capacity);
 

@@ -127,6 +127,8 @@ extern "C" {
     pub fn sde_test_conv_res(e: *mut sde_engine, naive: c_int, x: *const c_float, nb: c_int, hi: c_int, wi: c_int, cin: c_int,
                              w: *const c_float, bias: *const c_float, cout: c_int, ksize: c_int, residual: *const c_float, split: c_int,
                              out: *mut c_float, out_capacity: usize) -> c_int;
+    pub fn sde_test_geglu(e: *mut sde_engine, naive: c_int, x: *const c_float, m: c_int, k: c_int, w: *const c_float, bias: *const c_float,
+                          n: c_int, gelu_tanh: c_int, out: *mut c_float, out_capacity: usize) -> c_int;
     pub fn sde_test_attention(e: *mut sde_engine, naive: c_int, q: *const c_float, k: *const c_float, v: *const c_float,
                               nb: c_int, heads: c_int, sq: c_int, skv: c_int, d: c_int, out: *mut c_float, out_capacity: usize) -> c_int;
 }

@@ -338,3 +338,84 @@ def test_hooks_refuse_a_buffer_of_the_wrong_size(engine):
     st = L.sde_test_attention(engine._h, 0, q.ctypes.data, q.ctypes.data, q.ctypes.data, 1, 4, 64, 64, 16, guard.ctypes.data, 64 * 64 + 1)
     assert st == 1 and b"out_capacity" in L.sde_last_error()
     assert (guard == 7.0).all()
+
+
+# ---------------------------------------------------------------------------------------------- W-stationary streaming kernel (gemm_ws.hip)
+WS_CASES = [
+    # NB, H, W, Cin, Cout -- linears with K = 320 (160-column panels; anything else falls through to the tile kernels)
+    (1, 16, 16, 320, 160),       # one chunk, one panel
+    (1, 64, 32, 320, 320),       # 8 chunks (one per XCD), two panels side by side
+    (2, 64, 64, 320, 320),       # 32 chunks
+    (1, 48, 40, 320, 480),       # 1,920 rows = 7.5 chunks (ragged last chunk), three panels
+    (1, 33, 31, 320, 160),       # 1,023 rows: ragged wave tile
+    (4, 64, 64, 320, 960),       # the q / k / v projection shape of the 64x64 level (six panels: several passes)
+    (1, 40, 40, 320, 1920),      # twelve panels, ragged rows (1,600 = 12.5 chunks of 128)
+    (1, 40, 40, 640, 320),       # K = 640: not this kernel's (the hook falls through to the heuristic)
+    (1, 7, 5, 320, 160),         # fewer rows than one wave tile pair
+    (3, 50, 50, 320, 328),       # N not a multiple of the panel width (Npad = 480): masked columns
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+def test_linear_ws_kernel(engine, case):
+    NB, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    got = run_conv(engine, 6, x, w, b, 1, 1, 0)
+    xh = torch.from_numpy(x).half().double().reshape(-1, Cin)
+    ref = (xh @ torch.from_numpy(w).half().double().reshape(Cout, Cin).T + torch.from_numpy(b).double()).float().numpy().reshape(NB, H, W, Cout)
+    assert rel_l2(got, ref) < 2e-3, rel_l2(got, ref)
+    assert np.abs(got - ref).max() < 2e-2 * max(1.0, np.abs(ref).max())     # no stray rows / columns
+
+
+WS_RES_CASES = [
+    # NB, H, W, Cin, Cout -- residual in the epilogue, plain and split fp16 (the split-fp16 instance runs on 80-column panels)
+    (1, 64, 32, 320, 320), (1, 40, 40, 320, 320), (2, 64, 64, 320, 640), (1, 33, 31, 320, 160), (1, 20, 20, 320, 168),
+]
+
+
+@pytest.mark.parametrize("split", [0, 1])
+@pytest.mark.parametrize("case", WS_RES_CASES)
+def test_linear_ws_residual_epilogue(engine, case, split):
+    from diffusers_amd import _lib
+    NB, H, W, Cin, Cout = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31) + split)
+    x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    res = (rng.standard_normal((NB, H, W, Cout)) * 3).astype(np.float32)
+    out = np.empty((NB, H, W, Cout), np.float32)
+    _lib.check(_lib.lib().sde_test_conv_res(engine._h, 6, x.ctypes.data, NB, H, W, Cin, w.ctypes.data, b.ctypes.data, Cout, 1,
+                                            res.ctypes.data, split, out.ctypes.data, out.size))
+    lin = (torch.from_numpy(x).half().double().reshape(-1, Cin) @ torch.from_numpy(w).half().double().reshape(Cout, Cin).T
+           + torch.from_numpy(b).double()).numpy().reshape(NB, H, W, Cout)
+    if split:
+        assert rel_l2(out, lin + res.astype(np.float64)) < 2e-5
+    else:
+        assert rel_l2(out, lin + torch.from_numpy(res).half().double().numpy()) < 5e-4
+
+
+GEGLU_CASES = [
+    # M, K, N, tanh -- N = value | gate rows; N % 320 == 0: rows interleaved in fours (256x320 kernel, W-stationary kernel)
+    (1024, 64, 320, 0), (2048, 320, 2560, 0), (1600, 320, 640, 1), (4096, 640, 5120, 0), (1000, 640, 640, 0), (300, 128, 320, 1), (333, 320, 320, 0), (70, 640, 960, 1),
+]
+
+
+@pytest.mark.parametrize("kern", [0, 2, 6])
+@pytest.mark.parametrize("case", GEGLU_CASES)
+def test_geglu_projection(engine, case, kern):
+    """The GEGLU projection with the gate product in the epilogue, on the heuristic's choice, the 256x320 kernel and the W-stationary kernel."""
+    from diffusers_amd import _lib
+    M, K, N, tanh = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32)
+    out = np.empty((M, N // 2), np.float32)
+    _lib.check(_lib.lib().sde_test_geglu(engine._h, kern, x.ctypes.data, M, K, w.ctypes.data, b.ctypes.data, N, tanh, out.ctypes.data, out.size))
+    y = torch.from_numpy(x).half().double() @ torch.from_numpy(w).half().double().T + torch.from_numpy(b).double()
+    a, g = y[:, :N // 2], y[:, N // 2:]
+    ref = (a * (F.gelu(g, approximate="tanh") if tanh else F.gelu(g))).numpy()
+    assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
