@@ -113,6 +113,7 @@ ROCPROF_SYMBOL = {
     "gemm_mfma_ldw128": "gemm_midl_kernel<false, false, LO, 128>", "conv3x3_mfma_halo": "gemm_midh_kernel<LO, UPS, NT>",
     "conv3x3_mfma": "gemm_mfma_kernel<BM, BN, true>", "gemm_mfma": "gemm_mfma_kernel<BM, BN, false>",
     "splitk_reduce": "splitk_reduce_kernel",
+    "gemm_mfma_ws": "gemm_ws_kernel<5, NT, MT, EPI, R, WAVES>", "gemm_geglu_mfma_ws": "gemm_ws_kernel<5, NT, MT, EPI, R, WAVES>",
 }
 
 
@@ -122,27 +123,79 @@ def rocprof_symbol(cls):
 
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as children and relay rank 0's JSON line.
-    Runs before this process has initialised the GPU (children are fresh interpreters, not forks of a GPU process)."""
+    Runs before this process has initialised the GPU (children are fresh interpreters, not forks of a GPU process).
+    The ranks are supervised: every rank's output goes to a log of its own, the first rank that exits non-zero ends the job (the others
+    would sit in the rendezvous or in an all_reduce for ever) with that rank's exit code and the tail of its log, and the whole job has
+    a time limit (SDE_BENCH_TIMEOUT seconds, default 1500)."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    lines = [ln for ln in (out or "").splitlines() if ln.startswith("{")]
-    if lines:
-        print(lines[-1])
-    rc = max(abs(c) for c in codes)
-    if rc or not lines:
-        print(f"[bench] rank exit codes {codes}", file=sys.stderr)
-    sys.exit(rc if rc else (0 if lines else 1))
+    import tempfile
+    logdir = tempfile.mkdtemp(prefix="sde_bench_ranks_")
+    limit = float(os.environ.get("SDE_BENCH_TIMEOUT", "1500"))
+    last_err = None
+    for attempt in range(3):                    # the port is free when probed; another process may take it before rank 0 binds it
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs, logs = [], []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            out = open(os.path.join(logdir, f"rank{r}.out"), "w")
+            err = open(os.path.join(logdir, f"rank{r}.err"), "w")
+            logs.append((out, err))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out, stderr=err, text=True))
+        t0 = time.time()
+        failed = None
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                failed = bad[0]
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() - t0 > limit:
+                failed = -1
+                break
+            time.sleep(0.05)
+        if failed is not None:
+            for p in procs:                      # end the survivors: the exact children started above, nothing by pattern
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        for out, err in logs:
+            out.close(); err.close()
+        tail = lambda path: "".join(open(path).readlines()[-15:])
+        if failed is None:
+            lines = [ln for ln in open(os.path.join(logdir, "rank0.out")).read().splitlines() if ln.startswith("{")]
+            sys.stderr.write(open(os.path.join(logdir, "rank0.err")).read())
+            if lines:
+                print(lines[-1])
+                sys.exit(0)
+            print("[bench] rank 0 printed no result line", file=sys.stderr)
+            sys.exit(1)
+        if failed == -1:
+            print(f"[bench] the {n}-rank job exceeded {limit:.0f} s and was ended; rank logs under {logdir}", file=sys.stderr)
+            for r in range(n):
+                sys.stderr.write(f"---- rank {r} stderr (tail)\n{tail(os.path.join(logdir, f'rank{r}.err'))}")
+            sys.exit(124)
+        rc = procs[failed].returncode
+        err_tail = tail(os.path.join(logdir, f"rank{failed}.err"))
+        if "Address already in use" in err_tail and attempt < 2:      # lost the race for the probed port: a fresh port, once more
+            last_err = err_tail
+            continue
+        print(f"[bench] rank {failed} exited with code {rc}; the other ranks were ended.  Its output (tail; all logs under {logdir}):", file=sys.stderr)
+        sys.stderr.write(tail(os.path.join(logdir, f"rank{failed}.out")))
+        sys.stderr.write(err_tail)
+        sys.exit(abs(rc) or 1)
+    print(f"[bench] no free rendezvous port after 3 attempts: {last_err}", file=sys.stderr)
+    sys.exit(1)
 
 
 def main():
@@ -173,6 +226,9 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SDE_BENCH_DEBUG"]), exit=True)
     rank = int(os.environ.get("RANK", "0"))
+    if os.environ.get("SDE_BENCH_TEST_FAIL_RANK") == str(rank):      # tests/test_bench_launch.py: a rank that dies before the rendezvous
+        print("injected start-up failure", file=sys.stderr)
+        sys.exit(7)
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
@@ -352,10 +408,11 @@ def main():
             g["launches"] += st["launches"]
         sym, dom = max(by_sym.items(), key=lambda kv: kv[1]["total_ms"])
         # HBM-side bytes per launch of that kernel: PMC counters cannot be read from inside this process, so the figure comes from the
-        # committed rocprofv3 --pmc passes over this same workload (profiles/r2_pmc_traffic.json, FETCH_SIZE / WRITE_SIZE in separate runs)
+        # committed rocprofv3 --pmc passes over this same workload, 30 denoise steps (profiles/r3_pmc_traffic.json, FETCH_SIZE / WRITE_SIZE in separate runs)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["symbols"]
+            pmc_path = next(p for p in (os.path.join(ROOT, "profiles", f) for f in ("r3_pmc_traffic.json", "r2_pmc_traffic.json")) if os.path.exists(p))
+            pmc = json.load(open(pmc_path))["symbols"]
             v = pmc.get(sym)
             if v:
                 traffic = round((v["fetch_MB_per_launch_corrected_x2"] + v["write_MB_per_launch"]) * 1e6)
@@ -385,7 +442,7 @@ def main():
                     f"(UNet batch {2 * args.batch}), fp16, + batched VAE decode; random-init weights, text length 77")
     per_image_tflop = (2 * args.denoise_steps * UNET_GFLOP_PER_SAMPLE + VAE_GFLOP_PER_IMAGE) / 1e3
     out = {
-        "metric": "images/sec (SD1.5 512x512, 30 steps, fp16)", "value": round(value, 4), "unit": "images/sec",
+        "metric": f"images/sec (SD1.5 512x512, {args.denoise_steps} steps, fp16)", "value": round(value, 4), "unit": "images/sec",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2),
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f16",
         "data": "rehearsal: a sleep stands in for the engine, NOT a measurement" if args.rehearse else "synthetic",

@@ -38,6 +38,7 @@ class SchedCfg(C.Structure):
 
 CALLBACK = C.CFUNCTYPE(C.c_int, C.c_int, C.c_float, c_float_p, C.c_size_t, C.c_void_p)
 EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)   # sde_exchange_fn
+EXCHANGE_STREAM = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p)   # sde_exchange_stream_fn
 
 
 class Txt2ImgOpts(C.Structure):
@@ -49,7 +50,8 @@ class Txt2ImgOpts(C.Structure):
                 ("callback", CALLBACK), ("callback_user", C.c_void_p), ("noise_pred_out", C.c_void_p),
                 ("latents_out", C.c_void_p), ("final_latents_out", C.c_void_p),
                 ("cfg_half", C.c_int), ("exchange", EXCHANGE), ("exchange_user", C.c_void_p),
-                ("trace_rows", C.c_int), ("step_noise_rows", C.c_int), ("start_step", C.c_int)]
+                ("trace_rows", C.c_int), ("step_noise_rows", C.c_int), ("start_step", C.c_int),
+                ("exchange_stream", EXCHANGE_STREAM)]
 
 
 class StepOutput(C.Structure):

@@ -893,7 +893,7 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
         // CFG-pair split: this engine runs one half of the CFG batch; the peer's half arrives through the exchange hook
         const int half = o->cfg_half;
         SDE_REQUIRE(half >= 0 && half <= 2, SDE_ERR_INVALID_ARGUMENT, "cfg_half must be 0, 1 or 2");
-        SDE_REQUIRE(!half || (cfg && o->exchange), SDE_ERR_INVALID_ARGUMENT, "cfg_half needs guidance_scale > 1 and an exchange hook");
+        SDE_REQUIRE(!half || (cfg && (o->exchange || o->exchange_stream)), SDE_ERR_INVALID_ARGUMENT, "cfg_half needs guidance_scale > 1 and an exchange hook");
         const int Nu = half ? B : N;                 // UNet batch on this engine
         const size_t half_off = half == 2 ? 1 : 0;   // which half of [2B] this engine owns
         const size_t per = (size_t)B * C * h * w;
@@ -1005,7 +1005,11 @@ sde_status sde_txt2img_run(sde_engine* e, sde_scheduler* sch, const sde_txt2img_
                 if (!o->callback(pending_i, pending_t, e->preview->host.as<float>(), pending_n, o->callback_user)) { stopped = true; break; }
             }
             ++unet_calls;
-            if (half) {
+            if (half && o->exchange_stream) {
+                // stream-ordered: the hook enqueues the peer transfer on the engine's stream (or makes it wait); nothing drains
+                SDE_REQUIRE(o->exchange_stream(e->model_out.as<float>(), per, (int)half_off, (void*)st, o->exchange_user) != 0, SDE_ERR_EXCHANGE,
+                            "CFG-pair exchange hook failed at step " + std::to_string(i));
+            } else if (half) {
                 HIP_CHECK(hipStreamSynchronize(st));
                 SDE_REQUIRE(o->exchange(e->model_out.as<float>(), per, (int)half_off, o->exchange_user) != 0, SDE_ERR_EXCHANGE,
                             "CFG-pair exchange hook failed at step " + std::to_string(i));

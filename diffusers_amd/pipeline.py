@@ -349,9 +349,23 @@ class StableDiffusionTxt2ImgOptions:
                     pair_errors.append(exc)
                     return 0
 
-            xfn = _lib.EXCHANGE(xchg)
-            keep.append(xfn)
-            o.cfg_half, o.exchange = cfg_pair.half + 1, xfn
+            def xchg_stream(ptr, half_elems, my_half, stream, _user):
+                try:
+                    cfg_pair.exchange_on_stream(ptr, half_elems, my_half, stream)
+                    return 1
+                except Exception as exc:
+                    pair_errors.append(exc)
+                    return 0
+
+            o.cfg_half = cfg_pair.half + 1
+            if getattr(cfg_pair, "stream_ordered", False):      # the transport can be enqueued on the engine's stream: no per-step drain
+                xsf = _lib.EXCHANGE_STREAM(xchg_stream)
+                keep.append(xsf)
+                o.exchange_stream = xsf
+            else:
+                xfn = _lib.EXCHANGE(xchg)
+                keep.append(xfn)
+                o.exchange = xfn
         st = _lib.RunStats()
         try:
             _lib.check(L.sde_txt2img_run(session._h, scheduler._h, C.byref(o), images_ptr, C.byref(st)))

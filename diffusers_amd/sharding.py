@@ -69,6 +69,9 @@ class CfgPair:
             raise ValueError("a CFG pair is a group of exactly two ranks")
         if dist is not None and dist.get_rank(group) != half:
             raise ValueError("group order must be (unconditional rank, text rank)")
+        # RCCL collectives can be enqueued behind the engine's stream (sde_exchange_stream_fn): no host synchronisation per step
+        self.stream_ordered = self.backend == "nccl"
+        self._gather_buf = None
 
     def gather(self, full):
         """``full``: tensor [2, n] (device or CPU) whose row ``self.half`` is filled; fills the other row."""
@@ -84,6 +87,23 @@ class CfgPair:
             self.dist.all_gather(parts, host, group=self.group)
             full[1 - self.half].copy_(parts[1 - self.half])
         return full
+
+    def exchange_on_stream(self, ptr: int, half_elems: int, my_half: int, stream: int):
+        """The engine's sde_exchange_stream_fn (nccl backend): ``stream`` is the engine's hipStream_t.  The all-gather is issued with
+        that stream current, so RCCL's own stream waits for the UNet call already enqueued on it, and ``work.wait()`` makes the
+        engine's stream wait for the collective -- stream-side dependencies only, the host returns at once."""
+        import torch
+        if my_half != self.half:
+            raise RuntimeError(f"engine runs half {my_half}, pair object was built for half {self.half}")
+        dev = self.device if self.device is not None else torch.device("cuda", torch.cuda.current_device())
+        ext = torch.cuda.ExternalStream(int(stream), device=dev)
+        with torch.cuda.stream(ext):
+            full = torch.as_tensor(_DevicePtr(ptr, 2 * half_elems), device=dev).view(2, half_elems)
+            if self._gather_buf is None or self._gather_buf.shape != full.shape:
+                self._gather_buf = torch.empty_like(full)
+            work = self.dist.all_gather_into_tensor(self._gather_buf.view(-1), full[self.half].contiguous().view(-1), group=self.group, async_op=True)
+            work.wait()                                   # a stream wait (current stream <- RCCL's), not a host wait
+            full[1 - self.half].copy_(self._gather_buf[1 - self.half])
 
     def exchange(self, ptr: int, half_elems: int, my_half: int):
         """The engine's sde_exchange_fn: ``ptr`` = device f32 [2][half_elems], engine stream idle on entry; returns

@@ -99,10 +99,11 @@ sde_status sde_vae_decoder_run(sde_engine* e, const float* latent_sample, int B,
 /* `approximate_decode_latents` (impl_main.rs:385-395): 4->3 channel linear map + clamp -> f32 [B,h,w,3]. */
 sde_status sde_approximate_decode(sde_engine* e, const float* latents, int B, int h, int w, float* images_nhwc);
 
-/* The same as sde_approximate_decode for callers that cannot allocate device memory (code between hipStreamBeginCapture and
- * EndCapture, tight serving loops, harnesses that forbid hipMalloc): it has NO counterpart in the reference.  It calls no
- * hipMalloc / hipFree: the two staging tensors live in a static device array of SDE_NOALLOC_SCRATCH_BYTES that every GPU the
- * library runs on holds until the process ends.  B*h*w pixels need 256-aligned(16*B*h*w) + 12*B*h*w bytes; a larger request is
+/* The same as sde_approximate_decode for callers that cannot allocate device memory (tight serving loops, harnesses that forbid
+ * hipMalloc, processes whose memory pool is fixed at start-up): it has NO counterpart in the reference.  It calls no hipMalloc /
+ * hipFree: the two staging tensors live in a static device array of SDE_NOALLOC_SCRATCH_BYTES that every GPU the library runs on
+ * holds until the process ends.  It is a BLOCKING host-pointer call like its sibling (engine lock, two asynchronous copies on the
+ * engine's own stream, a stream synchronise), so it is not something to issue from inside a caller's stream capture.  B*h*w pixels need 256-aligned(16*B*h*w) + 12*B*h*w bytes; a larger request is
  * refused with SDE_ERR_INVALID_ARGUMENT (use sde_approximate_decode).  All calls on one GPU share that GPU's array: calls from
  * this process are serialised on it, calls that overlap in any other way (e.g. a copy of the library loaded twice) would race. */
 #define SDE_NOALLOC_SCRATCH_BYTES (8u << 20)
@@ -210,6 +211,14 @@ typedef int (*sde_callback_fn)(int step, float timestep, const float* payload, s
  * 2-rank RCCL all-gather over xGMI) and returns non-zero once that transfer has completed; 0 aborts the run.
  * No counterpart in the reference (single ORT session). */
 typedef int (*sde_exchange_fn)(float* d_model_out, size_t half_elems, int my_half, void* user);
+/* The stream-ordered form of the same hook (preferred when the transport can be enqueued): the engine does NOT synchronise its
+ * stream.  `hip_stream` is the engine's hipStream_t; the UNet call that fills half `my_half` has been enqueued on it, and the
+ * fused CFG + scheduler kernel that reads BOTH halves will be enqueued on it right after the hook returns.  The hook enqueues the
+ * transfer on that stream (ncclAllGather(..., stream)), or makes the stream wait for it (hipStreamWaitEvent), and returns at once:
+ * non-zero = enqueued, 0 aborts the run.  It must also order the peer's read of this engine's half before this stream's NEXT UNet
+ * call, which overwrites it (an all-gather on the stream does).  With this hook the denoise loop never drains the pipeline; with
+ * sde_exchange_fn it does so once per step.  If both are set this one is used. */
+typedef int (*sde_exchange_stream_fn)(float* d_model_out, size_t half_elems, int my_half, void* hip_stream, void* user);
 
 typedef struct sde_txt2img_opts {
     int height, width;          /* must be divisible by 8 (impl_txt2img.rs:251-253) */
@@ -247,6 +256,7 @@ typedef struct sde_txt2img_opts {
      * are taken as they are -- already noised by sde_scheduler_add_noise(0.18215 * encoded image, noise, timesteps[start_step]) --
      * instead of being multiplied by init_noise_sigma.  Callback / trace indices stay absolute (first call has step = start_step). */
     int start_step;
+    sde_exchange_stream_fn exchange_stream;   /* CFG-pair split, stream-ordered exchange (above); shares exchange_user */
 } sde_txt2img_opts;
 
 void sde_txt2img_opts_default(sde_txt2img_opts* o);

@@ -47,6 +47,8 @@ pub struct sde_sched_cfg { pub num_train_timesteps: c_int, pub beta_start: c_flo
 
 pub type sde_callback_fn = Option<unsafe extern "C" fn(c_int, c_float, *const c_float, usize, *mut c_void) -> c_int>;
 pub type sde_exchange_fn = Option<unsafe extern "C" fn(*mut c_float, usize, c_int, *mut c_void) -> c_int>;
+/// stream-ordered form: (d_model_out, half_elems, my_half, hipStream_t, user)
+pub type sde_exchange_stream_fn = Option<unsafe extern "C" fn(*mut c_float, usize, c_int, *mut c_void, *mut c_void) -> c_int>;
 
 #[repr(C)]
 pub struct sde_txt2img_opts { pub height: c_int, pub width: c_int, pub guidance_scale: c_float,
@@ -59,7 +61,7 @@ pub struct sde_txt2img_opts { pub height: c_int, pub width: c_int, pub guidance_
     pub cfg_half: c_int, pub exchange: sde_exchange_fn, pub exchange_user: *mut c_void,
     pub trace_rows: c_int, pub step_noise_rows: c_int,
     /// image-to-image: run timesteps[start_step..] from already-noised `init_latents` (no counterpart in the reference's run)
-    pub start_step: c_int }
+    pub start_step: c_int, pub exchange_stream: sde_exchange_stream_fn }
 
 #[repr(C)] #[derive(Clone, Copy, Default)]
 pub struct sde_run_stats { pub unet_calls: c_int, pub total_ms: c_float, pub unet_ms: c_float, pub vae_ms: c_float, pub host_enqueue_ms: c_float, pub unet_graph_launches: c_int }

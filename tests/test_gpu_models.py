@@ -396,8 +396,8 @@ def test_seeded_run_draws_the_reference_streams(pipe, kind):
     assert np.array_equal(seeded.noise_pred[0], injected.noise_pred[0])
 
 
-@pytest.mark.parametrize("kind,rescale", [("euler_a", None), ("dpmpp", 0.7)])
-def test_cfg_pair_split_matches_single_engine(tiny_model_dir, pipe, kind, rescale):
+@pytest.mark.parametrize("kind,rescale,stream_ordered", [("euler_a", None, False), ("dpmpp", 0.7, False), ("euler_a", None, True), ("dpmpp", 0.7, True)])
+def test_cfg_pair_split_matches_single_engine(tiny_model_dir, pipe, kind, rescale, stream_ordered):
     """SURVEY 8e / BASELINE config 3: two engines each run one half of the CFG batch and swap halves once per step through
     the sde_exchange_fn hook.  Here the two 'ranks' are two threads with two engines on the one GPU and the exchange is
     a device-to-device copy between them (tests/test_sharding_gloo.py covers the torch.distributed transport); the
@@ -413,6 +413,7 @@ def test_cfg_pair_split_matches_single_engine(tiny_model_dir, pipe, kind, rescal
 
         def __init__(self, half):
             super().__init__(None, None, half)
+            self.stream_ordered = stream_ordered
 
         def gather(self, full):
             ThreadPair.slots[self.half] = full[self.half].clone()
@@ -422,6 +423,29 @@ def test_cfg_pair_split_matches_single_engine(tiny_model_dir, pipe, kind, rescal
             torch.cuda.synchronize()
             ThreadPair.barrier.wait(timeout=60)
             return full
+
+        # sde_exchange_stream_fn: nothing synchronises a stream with the host.  Each engine's stream records "my half is ready", waits
+        # for the peer's event, copies the peer's half, records "I have read it" and waits for the peer's -- the host threads only
+        # rendezvous to hand the event objects over (what an all-gather enqueued on the stream does inside RCCL).
+        ready = [None, None]
+        taken = [None, None]
+
+        def exchange_on_stream(self, ptr, half_elems, my_half, stream):
+            from diffusers_amd.sharding import _DevicePtr
+            assert my_half == self.half
+            ext = torch.cuda.ExternalStream(int(stream))
+            with torch.cuda.stream(ext):
+                full = torch.as_tensor(_DevicePtr(ptr, 2 * half_elems), device="cuda").view(2, half_elems)
+                ThreadPair.slots[self.half] = full[self.half]
+                ev = torch.cuda.Event(); ev.record(ext)
+                ThreadPair.ready[self.half] = ev
+                ThreadPair.barrier.wait(timeout=60)
+                ext.wait_event(ThreadPair.ready[1 - self.half])
+                full[1 - self.half].copy_(ThreadPair.slots[1 - self.half])
+                ev2 = torch.cuda.Event(); ev2.record(ext)
+                ThreadPair.taken[self.half] = ev2
+                ThreadPair.barrier.wait(timeout=60)
+                ext.wait_event(ThreadPair.taken[1 - self.half])     # my next UNet call overwrites the half the peer is copying
 
     B, h, w, steps = 2, 16, 16, 5
     rng = np.random.default_rng(23)

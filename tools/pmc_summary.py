@@ -38,6 +38,8 @@ def kernel_class(name: str) -> str:
         return ("conv3x3_mfma_" if t and t[0] == "true" else "gemm_mfma_") + "256x160"
     if base == "gemm_midh_kernel":
         return "conv3x3_mfma_halo"
+    if base == "gemm_ws_kernel":          # <KT, NT, MT, EPI, HAS_R, WAVES>: EPI 2 = the GEGLU projection
+        return "gemm_geglu_mfma_ws" if len(t) > 3 and t[3] == "2" else "gemm_mfma_ws"
     if base == "gemm_mfma_kernel":
         conv = len(t) > 2 and t[2] == "true"
         return ("conv3x3_mfma_" if conv else "gemm_mfma_") + f"{t[0]}x{t[1]}" if len(t) > 1 else "gemm_mfma"
@@ -59,6 +61,8 @@ def symbol_key(name: str) -> str:
         return f"gemm_mid_kernel<{t[0]}, {'UPS' if t[0] == 'true' else t[1]}, {t[2]}, LO>"
     if base == "gemm_midh_kernel":
         return "gemm_midh_kernel<LO, UPS, NT>"
+    if base == "gemm_ws_kernel":
+        return "gemm_ws_kernel<5, NT, MT, EPI, R, WAVES>"
     if base == "gemm_mfma_kernel" and len(t) >= 3:
         return f"gemm_mfma_kernel<BM, BN, {t[2]}>"
     if base == "attn_mfma_kernel" and len(t) >= 2:
