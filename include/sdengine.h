@@ -51,7 +51,11 @@ typedef struct sde_engine_opts {
     int device_id;       /* HIP device ordinal (the new "native MI355X(device_id)" DiffusionDevice, lib.rs:81-107) */
     int dtype;           /* sde_dtype: activation/weight storage inside the engine; I/O is always f32.  SDE_F16 (default): MFMA kernels,
                           * fp32 accumulation, the benchmarked path.  SDE_F32: every tensor and every product in fp32 (plain kernels), the
-                          * precision of the reference's own graphs (sd2pyke.py:86,120-125); bar 1e-4.  SDE_BF16: not implemented (refused). */
+                          * precision of the reference's own graphs (sd2pyke.py:86,120-125); bar 1e-4.  SDE_BF16: not implemented (refused).
+                          * Limit of SDE_F16: its 1e-2 bar assumes every GroupNorm group holds >= 8 values (channels per group x H x W at the
+                          * deepest level).  SD v1.x / v2.x meet that from 16 x 16 pixel images on (40 channels per group at the deepest level);
+                          * a model with one channel per group and a 1 x 1 deepest level does not (fp16 rounding noise is multiplied by
+                          * rstd ~ eps^-1/2 = 316): errors of several 1e-2 were measured there -- use SDE_F32 for such models. */
     int force_naive;     /* 1 = run every contraction on the plain (non-MFMA) kernels (debug / cross-check) */
     int load_unet;       /* 0 skips unet.onnx  (engine then only serves sde_vae_decode) */
     int load_vae;        /* 0 skips vae_decoder.onnx */
