@@ -1,7 +1,7 @@
 // f32path.hip — the fp32 engine (sde_engine_opts.dtype = SDE_F32): every activation and weight is a float, every kernel below
 // computes in fp32.  It exists for the reference's own precision (its tensors and ORT graphs are f32: impl_txt2img.rs:262,283;
-// sd2pyke.py:86,120-125) and for the north-star's 1e-4 parity bar; it is a correctness path, not the benchmarked one: plain
-// LDS-tiled FMA GEMM / implicit-GEMM conv (no MFMA: gfx950 has no fp32 matrix rate worth the layout work at these sizes),
+// sd2pyke.py:86,120-125) and for the north-star's 1e-4 parity bar; it is a correctness path, not the benchmarked one: GEMM /
+// implicit-GEMM conv on v_mfma_f32_16x16x4_f32 tiles (fp32 operands; the plain LDS-tiled FMA kernel takes the shapes the tiles cannot),
 // two-pass attention, three-pass GroupNorm.  Same contracts as the fp16 launchers in kernels.h: the launchers there branch here when
 // LaunchCtx::f32 is set, with every `half_t*` argument actually addressing floats.
 #include "gemm_common.h"
@@ -104,6 +104,141 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmF p)
             }
         }
     }
+}
+
+// MFMA variant: v_mfma_f32_16x16x4_f32 (f32 operands, f32 accumulation: each product and sum is the same IEEE operation as the fmaf chain
+// of the plain kernel above, in another order).  256 threads = 2 x 2 waves, block tile BMT x BNT x 16, two LDS stages, the next slab's
+// global loads in flight over the current slab's MFMAs, one barrier per slab.
+//   * Both operands sit in LDS as [row][16 k + 4 pad] floats.  Lane (i = lane % 16, g = lane / 16) reads ONE b128 per 16-row tile and
+//     slab: k = 4g .. 4g+3 of row i.  MFMA number s of the slab takes component s from every lane, i.e. the hardware's "k = g" slot
+//     carries k = 4g + s: A and B use the same permutation, so the four MFMAs together cover the slab's 16 k once each.
+//   * A 16-float slab never straddles a tap, a 64-channel chunk or the concat boundary (launcher checks C0 % 16, ck % 16): tap and
+//     source select are wave-uniform per slab, the per-row pixel decomposition is done once per thread.
+template <int BMT, int BNT>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmF p)
+{
+    constexpr int LDT = 20;                            // 80-byte rows: b128 reads of 16 consecutive rows tile all 64 banks
+    constexpr int EA = BMT / 64, EB = BNT / 64;        // float4 loads per thread and slab
+    constexpr int TM = BMT / 32, TN = BNT / 32;        // 16 x 16 tiles per wave
+    __shared__ __align__(16) float As[2][BMT * LDT];
+    __shared__ __align__(16) float Bs[2][BNT * LDT];
+    const int z = blockIdx.z;
+    const float* A0 = p.A0 + z * p.sA;
+    const float* A1 = p.A1 ? p.A1 + z * p.sA : nullptr;
+    const float* Wp = p.W + z * p.sW;
+    const int m0 = blockIdx.x * BMT, n0 = blockIdx.y * BNT;
+    const int tid = threadIdx.x, lrow = tid >> 2, kq = (tid & 3) * 4;
+    const int Ctot = p.C0 + p.C1, ck = (Ctot % 64 == 0) ? 64 : Ctot;
+    const int hw = p.Ho * p.Wo;
+
+    int iy0[EA], ix0[EA];
+    long long base[EA];                                // taps 1: the row itself (-1: past M); taps 9: first pixel of the row's image
+#pragma unroll
+    for (int e = 0; e < EA; ++e) {
+        const int m = m0 + lrow + 64 * e;
+        if (p.taps == 9) {
+            const int nb = m / hw, r = m - nb * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
+            iy0[e] = m < p.M ? oy * p.stride + p.coff - 1 : -(1 << 20);
+            ix0[e] = ox * p.stride + p.coff - 1;
+            base[e] = (long long)nb * p.Hs * p.Ws;
+        } else {
+            iy0[e] = ix0[e] = 0;
+            base[e] = m < p.M ? m : -1;
+        }
+    }
+    floatx4 ra[EA], rb[EB];
+    auto fetch = [&](int k0) {
+        int tap = 0, c = k0;
+        if (p.taps == 9) {
+            const int chunk = k0 / (9 * ck), rem = k0 - chunk * 9 * ck;
+            tap = rem / ck;
+            c = chunk * ck + (rem - tap * ck);
+        }
+        const bool first = c < p.C0;
+        const float* src = first ? A0 + c + kq : A1 + (c - p.C0) + kq;
+        const int ld = first ? p.lda0 : p.lda1;
+        const int dy = tap / 3, dx = tap - 3 * dy;
+#pragma unroll
+        for (int e = 0; e < EA; ++e) {
+            long long pix = base[e];
+            bool ok = pix >= 0;
+            if (p.taps == 9) {
+                const int iy = iy0[e] + dy, ix = ix0[e] + dx;
+                ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                pix += (long long)(iy >> p.ups) * p.Ws + (ix >> p.ups);
+            }
+            ra[e] = ok ? *(const floatx4*)(src + pix * ld) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int e = 0; e < EB; ++e) {
+            const int n = n0 + lrow + 64 * e;
+            rb[e] = n < p.Npad ? *(const floatx4*)(Wp + (long long)n * p.K + k0 + kq) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int e = 0; e < EA; ++e) *(floatx4*)&As[buf][(lrow + 64 * e) * LDT + kq] = ra[e];
+#pragma unroll
+        for (int e = 0; e < EB; ++e) *(floatx4*)&Bs[buf][(lrow + 64 * e) * LDT + kq] = rb[e];
+    };
+
+    const int lane = tid & 63, wv = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int wm = (wv >> 1) * (BMT / 2), wn = (wv & 1) * (BNT / 2);
+    floatx4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    const int nk = p.K / 16;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch((kt + 1) * 16);
+        floatx4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *(const floatx4*)&As[buf][(wm + i * 16 + li) * LDT + lg * 4];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *(const floatx4*)&Bs[buf][(wn + j * 16 + li) * LDT + lg * 4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        if (kt + 1 < nk) stash(buf ^ 1);
+        __syncthreads();
+    }
+    // accumulator layout of the 16x16 MFMA: lane (li, lg), register r = element (row 4 lg + r, column li)
+    const long long zD = z * p.sD, zR = z * p.sR;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + j * 16 + li;
+            if (n >= p.N) continue;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm + i * 16 + lg * 4 + r;
+                if (m >= p.M) continue;
+                float x = acc[i][j][r] * p.alpha + bv;
+                if (p.epi == EPI_STD) {
+                    if (p.R) x += p.R[zR + (long long)m * p.ldr + n];
+                    p.D[zD + (long long)m * p.ldd + n] = x;
+                } else if (p.epi == EPI_NCHW_F32) {
+                    const int nb = m / hw, pix = m - nb * hw;
+                    p.Df[zD + ((long long)nb * p.N + n) * hw + pix] = x;
+                } else if (p.epi == EPI_IMAGE) {
+                    x = x / 2.0f + 0.5f;
+                    p.Df[zD + (long long)m * p.N + n] = fminf(fmaxf(x, 0.0f), 1.0f);
+                } else {   // EPI_TRANS
+                    p.D[zD + (long long)n * p.ldd + m] = x;
+                }
+            }
+        }
 }
 
 // GEGLU on an un-fused projection: Y[m][j] = X[m][j] * gelu(X[m][half + j]) (first half = value, second half = gate)
@@ -323,7 +458,17 @@ void f32_launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     p.D = (float*)a.D; p.Df = a.Df; p.ldd = a.ldd; p.epi = a.epi; p.alpha = a.alpha; p.sA = a.sA; p.sW = a.sW; p.sD = a.sD; p.sR = a.sR;
     ProfScope ps(ctx, a.taps == 9 ? "conv3x3_f32" : "gemm_f32", 2.0 * a.M * (double)a.N * a.K * a.batch,
                  4.0 * a.batch * ((double)a.M * a.K / (a.taps == 9 ? 9.0 : 1.0) + (double)a.N * a.K + (double)a.M * a.N));
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a.M, BM), cdiv(a.N, BN), a.batch), dim3(256), 0, ctx.stream, p);
+    // MFMA tiles need 16-float slabs that stay inside one tap / chunk / concat source, and 16-byte aligned rows
+    const int Ctot = a.C0 + a.C1, ckk = (Ctot % 64 == 0) ? 64 : Ctot;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    static const int mfma_env = [] { const char* v = getenv("SDE_F32_MFMA"); return v ? atoi(v) : 1; }();   // 0: plain FMA kernel everywhere
+    const bool mfma = mfma_env && !ctx.force_naive && a.K % 16 == 0 && a.C0 % 16 == 0 && a.C1 % 16 == 0 && (a.taps == 1 || ckk % 16 == 0) &&
+                      a.lda0 % 4 == 0 && (!a.A1 || a.lda1 % 4 == 0) && al16(a.A0) && al16(a.A1) && al16(a.W) && a.sA % 4 == 0 && a.sW % 4 == 0;
+    if (!mfma) hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a.M, BM), cdiv(a.N, BN), a.batch), dim3(256), 0, ctx.stream, p);
+    else if ((long long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch >= 192)
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<128, 128>), dim3(cdiv(a.M, 128), cdiv(a.N, 128), a.batch), dim3(256), 0, ctx.stream, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_mfma_kernel<64, 64>), dim3(cdiv(a.M, 64), cdiv(a.N, 64), a.batch), dim3(256), 0, ctx.stream, p);
     HIP_CHECK(hipGetLastError());
 }
 

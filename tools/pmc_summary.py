@@ -2,7 +2,13 @@
 """Per-kernel-class summary of a `rocprofv3 --pmc ... --kernel-trace --output-format csv` counter_collection CSV.
 
 usage: python tools/pmc_summary.py <counter_collection.csv> [out.json]
-       python tools/pmc_summary.py --traffic <FETCH_SIZE pass csv> <WRITE_SIZE pass csv> <out.json> [source note]
+       python tools/pmc_summary.py --traffic <FETCH_SIZE pass csv> <WRITE_SIZE pass csv> <out.json> [source note] [unet_weight]
+
+--traffic with unet_weight W (e.g. 15): the passes ran FEWER denoise steps than the bench (2 instead of 30: a 30-step run under --pmc
+crashed inside the profiler, gpurun_out/pmc_f.log), so every dispatch up to the last cfg_scheduler_step launch (the denoise loop) is
+counted W times, bytes and launches alike, and the VAE decode after it once: per-launch averages of a kernel class are then those of
+the bench's own launch mix (UNet : VAE launches = 30 : 1).  Shapes are deterministic, so this is exact, not an estimate.  "phases" in
+the output keeps the un-mixed per-phase figures.
 
 Counters are summed per kernel class over all dispatches; durations are End-Start of the same dispatches (under PMC
 collection, i.e. slower than un-profiled).  Derived figures:
@@ -81,12 +87,14 @@ def engine_class(name: str, dur_ns: float, split: dict) -> str:
             "cfg_step": "cfg_scheduler_step", "splitk_reduce": "splitk_reduce", "gemv": "gemv_time_mlp"}.get(m.group(1), k) if m else k
 
 
-def traffic(fetch_csv: str, write_csv: str, out_path: str, source: str):
-    """profiles/r1_pmc_traffic.json: HBM-side bytes per launch per engine kernel class from two separate --pmc passes."""
+def traffic(fetch_csv: str, write_csv: str, out_path: str, source: str, unet_weight: float = 1.0):
+    """profiles/r*_pmc_traffic.json: HBM-side bytes per launch per engine kernel class from two separate --pmc passes."""
     res = defaultdict(lambda: defaultdict(float))
     sym = defaultdict(lambda: defaultdict(float))
+    phase = defaultdict(lambda: defaultdict(float))
     for path, counter, key in ((fetch_csv, "FETCH_SIZE", "fetch_kb"), (write_csv, "WRITE_SIZE", "write_kb")):
         rows = [r for r in csv.DictReader(open(path, newline="")) if r["Counter_Name"] == counter]
+        loop_end = max((int(r["Dispatch_Id"]) for r in rows if "cfg_step" in r["Kernel_Name"]), default=-1)
         split = {}
         for r in rows:
             k, d = kernel_class(r["Kernel_Name"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
@@ -94,13 +102,23 @@ def traffic(fetch_csv: str, write_csv: str, out_path: str, source: str):
             split[k] = (min(lo, d), max(hi, d))
         for r in rows:
             d = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            in_loop = int(r["Dispatch_Id"]) <= loop_end
+            wgt = unet_weight if in_loop else 1.0
             e = res[engine_class(r["Kernel_Name"], d, split)]
-            e[key] += float(r["Counter_Value"])
-            e[key + "_n"] += 1
+            e[key] += wgt * float(r["Counter_Value"])
+            e[key + "_n"] += wgt
             g = sym[symbol_key(r["Kernel_Name"])]
-            g[key] += float(r["Counter_Value"])
-            g[key + "_n"] += 1
-    out = {"source": source, "kernels": {}, "symbols": {}}
+            g[key] += wgt * float(r["Counter_Value"])
+            g[key + "_n"] += wgt
+            h = phase[symbol_key(r["Kernel_Name"]) + (" [denoise loop]" if in_loop else " [vae decode]")]
+            h[key] += float(r["Counter_Value"])
+            h[key + "_n"] += 1
+    out = {"source": source, "kernels": {}, "symbols": {}, "phases": {}}
+    for k, e in sorted(phase.items()):
+        if e.get("fetch_kb_n") and e.get("write_kb_n"):
+            out["phases"][k] = {"launches_in_pass": int(e["fetch_kb_n"]),
+                                "fetch_MB_per_launch_corrected_x2": round(2 * e["fetch_kb"] * 1024 / e["fetch_kb_n"] / 1e6, 2),
+                                "write_MB_per_launch": round(e["write_kb"] * 1024 / e["write_kb_n"] / 1e6, 2)}
     for k, e in sorted(sym.items(), key=lambda kv: -(kv[1]["fetch_kb"] + kv[1]["write_kb"])):
         if e.get("fetch_kb_n") and e.get("write_kb_n"):
             f = e["fetch_kb"] * 1024 / e["fetch_kb_n"] / 1e6
@@ -120,7 +138,7 @@ def traffic(fetch_csv: str, write_csv: str, out_path: str, source: str):
 
 def main():
     if sys.argv[1] == "--traffic":
-        return traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "")
+        return traffic(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5] if len(sys.argv) > 5 else "", float(sys.argv[6]) if len(sys.argv) > 6 else 1.0)
     path = sys.argv[1]
     agg = defaultdict(lambda: defaultdict(float))
     seen = set()
