@@ -1191,24 +1191,28 @@ sde_status sde_test_conv(sde_engine* e, int naive, const float* x, int NB, int H
         require_out_capacity("sde_test_conv", no, out_capacity,
                              "[" + std::to_string(NB) + "," + std::to_string(Ho) + "," + std::to_string(Wo) + "," + std::to_string(Cout) + "]");
         const int Npad = gemm_npad(Cout), K = taps * Cin;
+        // naive 7 / 8: the fp32 engine's kernels (f32path.hip), MFMA tiles / plain FMA: no fp16 anywhere, operands stay floats
+        const bool f32k = naive == 7 || naive == 8;
+        ctx.f32 = f32k; if (naive == 8) ctx.force_naive = true;
+        const size_t es = f32k ? 4 : 2;
         DevBuf dxf, dxh, dwf, dwh, dbias, doh, dof;
-        dxf.ensure(nx * 4); dxh.ensure(nx * 2); dwf.ensure(nw * 4); dwh.ensure((size_t)Npad * K * 2); doh.ensure(no * 2); dof.ensure(no * 4);
+        dxf.ensure(nx * 4); dxh.ensure(nx * 2); dwf.ensure(nw * 4); dwh.ensure((size_t)Npad * K * es); doh.ensure(no * 2); dof.ensure(no * 4);
         HIP_CHECK(hipMemcpy(dxf.p, x, nx * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(dwf.p, w, nw * 4, hipMemcpyHostToDevice));
-        HIP_CHECK(hipMemsetAsync(dwh.p, 0, (size_t)Npad * K * 2, e->stream));
+        HIP_CHECK(hipMemsetAsync(dwh.p, 0, (size_t)Npad * K * es, e->stream));
         if (bias) { dbias.ensure((size_t)Cout * 4); HIP_CHECK(hipMemcpy(dbias.p, bias, (size_t)Cout * 4, hipMemcpyHostToDevice)); }
-        launch_f32_to_f16(ctx, dxf.as<float>(), dxh.as<half_t>(), (int64_t)nx);
+        if (!f32k) launch_f32_to_f16(ctx, dxf.as<float>(), dxh.as<half_t>(), (int64_t)nx);
         RepackArgs r;
         r.src = dwf.p; r.src_is_f16 = 0; r.O = Cout; r.I = Cin; r.KH = ksize; r.KW = ksize; r.in_out = 0; r.dst = dwh.as<half_t>();
-        r.dst_row0 = 0; r.Ipad = Cin; r.i0 = 0; r.Kdst = K;
+        r.dst_row0 = 0; r.Ipad = Cin; r.i0 = 0; r.Kdst = K; r.dst_f32 = f32k ? 1 : 0;
         launch_repack(ctx, r);
         GemmArgs g;
-        g.A0 = dxh.as<half_t>(); g.lda0 = Cin; g.C0 = Cin; g.taps = taps; g.stride = ksize == 3 ? stride : 1; g.ups = ksize == 3 ? (upsample != 0) : 0;
+        g.A0 = f32k ? dxf.as<half_t>() : dxh.as<half_t>(); g.lda0 = Cin; g.C0 = Cin; g.taps = taps; g.stride = ksize == 3 ? stride : 1; g.ups = ksize == 3 ? (upsample != 0) : 0;
         g.coff = asym ? 1 : 0;
         g.Hi = Hv; g.Wi = Wv; g.Ho = Ho; g.Wo = Wo; g.M = NB * Ho * Wo; g.N = Cout; g.K = K;
-        g.W = dwh.as<half_t>(); g.Npad = Npad; g.bias = bias ? dbias.as<float>() : nullptr; g.D = doh.as<half_t>(); g.ldd = Cout;
+        g.W = dwh.as<half_t>(); g.Npad = Npad; g.bias = bias ? dbias.as<float>() : nullptr; g.D = f32k ? dof.as<half_t>() : doh.as<half_t>(); g.ldd = Cout;
         launch_gemm(ctx, g);
-        launch_f16_to_f32(ctx, doh.as<half_t>(), dof.as<float>(), (int64_t)no);
+        if (!f32k) launch_f16_to_f32(ctx, doh.as<half_t>(), dof.as<float>(), (int64_t)no);
         HIP_CHECK(hipStreamSynchronize(e->stream));
         HIP_CHECK(hipMemcpy(out, dof.p, no * 4, hipMemcpyDeviceToHost));
     });
@@ -1309,7 +1313,8 @@ sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const fl
                              "[" + std::to_string(NB) + "," + std::to_string(Sq) + "," + std::to_string(heads * d) + "]");
         EngineLock lk(e);
         engine_activate(e);
-        LaunchCtx ctx = e->ctx; ctx.f32 = false; ctx.force_naive = naive != 0;
+        const bool f32k = naive == 7 || naive == 8;          // the fp32 engine's kernels: 7 = MFMA, 8 = plain
+        LaunchCtx ctx = e->ctx; ctx.f32 = f32k; ctx.force_naive = f32k ? naive == 8 : naive != 0;
         const int C = heads * d;
         const size_t nq = (size_t)NB * Sq * C, nk = (size_t)NB * Skv * C;
         DevBuf f, qh, kh, vh, oh, of;
@@ -1319,12 +1324,17 @@ sde_status sde_test_attention(sde_engine* e, int naive, const float* q, const fl
             launch_f32_to_f16(ctx, f.as<float>(), dst.as<half_t>(), (int64_t)n);
             HIP_CHECK(hipStreamSynchronize(e->stream));
         };
-        up(q, nq, qh); up(k, nk, kh); up(v, nk, vh);
+        if (f32k) {
+            qh.ensure(nq * 4); kh.ensure(nk * 4); vh.ensure(nk * 4);
+            HIP_CHECK(hipMemcpy(qh.p, q, nq * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(kh.p, k, nk * 4, hipMemcpyHostToDevice));
+            HIP_CHECK(hipMemcpy(vh.p, v, nk * 4, hipMemcpyHostToDevice));
+        } else { up(q, nq, qh); up(k, nk, kh); up(v, nk, vh); }
         AttnArgs a;
-        a.Q = qh.as<half_t>(); a.K = kh.as<half_t>(); a.V = vh.as<half_t>(); a.O = oh.as<half_t>();
+        a.Q = qh.as<half_t>(); a.K = kh.as<half_t>(); a.V = vh.as<half_t>(); a.O = f32k ? of.as<half_t>() : oh.as<half_t>();
         a.ldq = a.ldk = a.ldv = a.ldo = C; a.NB = NB; a.heads = heads; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.0f / sqrtf((float)d);
         launch_attention(ctx, a);
-        launch_f16_to_f32(ctx, oh.as<half_t>(), of.as<float>(), (int64_t)nq);
+        if (!f32k) launch_f16_to_f32(ctx, oh.as<half_t>(), of.as<float>(), (int64_t)nq);
         HIP_CHECK(hipStreamSynchronize(e->stream));
         HIP_CHECK(hipMemcpy(out, of.p, nq * 4, hipMemcpyDeviceToHost));
     });

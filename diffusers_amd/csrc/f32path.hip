@@ -24,6 +24,7 @@ struct GemmF {
     const float* bias; const float* R; int ldr;
     float* D; float* Df; int ldd; int epi; float alpha;
     long long sA, sW, sD, sR;
+    int splitk; float* ws;     // MFMA kernel, batch 1: splitk > 1 = blockIdx.z owns a K range and leaves a raw fp32 partial tile in ws[z][M][N]
 };
 
 // element (m, k) of the implicit im2col matrix; k runs in the engine's weight order ((c / ck) * taps + tap) * ck + c % ck (kernels.h)
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmF p)
     constexpr int TM = BMT / 32, TN = BNT / 32;        // 16 x 16 tiles per wave
     __shared__ __align__(16) float As[2][BMT * LDT];
     __shared__ __align__(16) float Bs[2][BNT * LDT];
-    const int z = blockIdx.z;
+    const int z = p.splitk > 1 ? 0 : blockIdx.z;
     const float* A0 = p.A0 + z * p.sA;
     const float* A1 = p.A1 ? p.A1 + z * p.sA : nullptr;
     const float* Wp = p.W + z * p.sW;
@@ -190,11 +191,16 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmF p)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
-    stash(0);
+    int kt0 = 0, nk = p.K / 16;
+    if (p.splitk > 1) {
+        const int per = (nk + p.splitk - 1) / p.splitk;
+        kt0 = blockIdx.z * per;
+        nk = min(nk, kt0 + per);                       // the launcher keeps every range non-empty
+    }
+    fetch(kt0 * 16);
+    stash(kt0 & 1);
     __syncthreads();
-    const int nk = p.K / 16;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt0; kt < nk; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nk) fetch((kt + 1) * 16);
         floatx4 a[TM], b[TN];
@@ -212,6 +218,21 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmF p)
         __syncthreads();
     }
     // accumulator layout of the 16x16 MFMA: lane (li, lg), register r = element (row 4 lg + r, column li)
+    if (p.splitk > 1) {
+        float* wsz = p.ws + (long long)blockIdx.z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn + j * 16 + li;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm + i * 16 + lg * 4 + r;
+                    if (m < p.M && n < p.N) wsz[(long long)m * p.N + n] = acc[i][j][r];
+                }
+            }
+        return;
+    }
     const long long zD = z * p.sD, zR = z * p.sR;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -239,6 +260,31 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_kernel(GemmF p)
                 }
             }
         }
+}
+
+// split-K tail: adds the partial tiles in slice order (a fixed order: bit-reproducible) and applies the epilogue
+__global__ __launch_bounds__(256) void gemm_f32_splitk_reduce_kernel(GemmF p)
+{
+    const long long total = (long long)p.M * p.N;
+    const int hw = p.Ho * p.Wo;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int m = (int)(i / p.N), n = (int)(i - (long long)m * p.N);
+        float a = 0.f;
+        for (int z = 0; z < p.splitk; ++z) a += p.ws[z * total + i];
+        float x = a * p.alpha + (p.bias ? p.bias[n] : 0.f);
+        if (p.epi == EPI_STD) {
+            if (p.R) x += p.R[(long long)m * p.ldr + n];
+            p.D[(long long)m * p.ldd + n] = x;
+        } else if (p.epi == EPI_NCHW_F32) {
+            const int nb = m / hw, pix = m - nb * hw;
+            p.Df[((long long)nb * p.N + n) * hw + pix] = x;
+        } else if (p.epi == EPI_IMAGE) {
+            x = x / 2.0f + 0.5f;
+            p.Df[(long long)m * p.N + n] = fminf(fmaxf(x, 0.0f), 1.0f);
+        } else {
+            p.D[(long long)n * p.ldd + m] = x;
+        }
+    }
 }
 
 // GEGLU on an un-fused projection: Y[m][j] = X[m][j] * gelu(X[m][half + j]) (first half = value, second half = gate)
@@ -345,6 +391,144 @@ __global__ __launch_bounds__(256) void attn_f32_wide_kernel(AttnF p)
     for (int c = lane; c < d; c += 64) Or[c] = acc[c] * inv;
 }
 
+// MFMA attention in fp32 (v_mfma_f32_16x16x4_f32), online softmax.  One block = 4 waves x 32 queries of one (image, head); keys in tiles
+// of 32 staged through LDS as [key][DT*16 + 4] floats for both K and V (columns d .. DT*16 are zero), the next tile's global loads in
+// flight over the current tile's MFMAs.
+//   S^T[key][q] = K . Q^T : A = K rows (one b128 LDS read per 16 keys and 16-wide chunk of d: the lane's four values feed four MFMAs, the
+//                 same k-permutation as gemm_f32_mfma_kernel), B = the wave's Q fragments (registers, pre-multiplied by scale * log2 e).
+//                 The result leaves lane (li = query, lg) holding keys 4 lg + r: exactly the B-operand layout of the second product
+//   O^T[c][q]   = V^T . P^T: A = V[key = 4 lg + s][c = li] (four b32 LDS reads, row stride = 16 banks mod 64: conflict-free), B = P.
+// Row maxima are shared over the four lg groups with two shuffles; row sums are kept per lane and reduced once at the end.
+template <int DT>
+__global__ __launch_bounds__(256) void attn_f32_mfma_kernel(AttnF p)
+{
+    constexpr int KT = 32, LDK = DT * 16 + 4, QT = 2;
+    constexpr int NLD = (KT * DT * 4 + 255) / 256;            // float4 loads per thread, tile and operand
+    __shared__ __align__(16) float Ks[KT * LDK];
+    __shared__ __align__(16) float Vs[KT * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, li = lane & 15, lg = lane >> 4;
+    const int qblocks = (p.Sq + 127) / 128;
+    const int qb = blockIdx.x % qblocks, head = (blockIdx.x / qblocks) % p.heads, nb = blockIdx.x / (qblocks * p.heads);
+    const int d = p.d, d4 = d >> 2;
+    const float* Kb = p.K + (long long)nb * p.Skv * p.ldk + head * d;
+    const float* Vb = p.V + (long long)nb * p.Skv * p.ldv + head * d;
+    for (int i = tid; i < KT * LDK; i += 256) { Ks[i] = 0.f; Vs[i] = 0.f; }
+
+    const float qscale = p.scale * 1.44269504088896340736f;
+    const int q0 = qb * 128 + wv * 32;
+    floatx4 qf[QT][DT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int q = q0 + t * 16 + li;
+        const float* Qr = p.Q + ((long long)nb * p.Sq + min(q, p.Sq - 1)) * p.ldq + head * d;
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            const int col = c * 16 + lg * 4;
+            floatx4 v = col < d ? *(const floatx4*)(Qr + col) : floatx4{0.f, 0.f, 0.f, 0.f};
+            qf[t][c] = v * qscale;
+        }
+    }
+    floatx4 o[QT][DT];
+    float mx[QT], lsum[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        mx[t] = -INFINITY; lsum[t] = 0.f;
+#pragma unroll
+        for (int c = 0; c < DT; ++c) o[t][c] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    floatx4 rk[NLD], rv[NLD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int id = tid + e * 256, key = id / d4, c4 = id - key * d4;
+            const bool ok = key < KT && k0 + key < p.Skv;
+            rk[e] = ok ? *(const floatx4*)(Kb + (long long)(k0 + key) * p.ldk + c4 * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            rv[e] = ok ? *(const floatx4*)(Vb + (long long)(k0 + key) * p.ldv + c4 * 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int e = 0; e < NLD; ++e) {
+            const int id = tid + e * 256, key = id / d4, c4 = id - key * d4;
+            if (key < KT) { *(floatx4*)&Ks[key * LDK + c4 * 4] = rk[e]; *(floatx4*)&Vs[key * LDK + c4 * 4] = rv[e]; }
+        }
+    };
+    fetch(0);
+    __syncthreads();                       // zero fill done
+    for (int k0 = 0; k0 < p.Skv; k0 += KT) {
+        stash();
+        __syncthreads();
+        if (k0 + KT < p.Skv) fetch(k0 + KT);
+        floatx4 s[QT][2];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) { s[t][0] = floatx4{0.f, 0.f, 0.f, 0.f}; s[t][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                const floatx4 kf = *(const floatx4*)&Ks[(ks * 16 + li) * LDK + c * 16 + lg * 4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) s[t][ks] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[u], qf[t][c][u], s[t][ks], 0, 0, 0);
+            }
+        // lane (li, lg) holds, for query li of each q-tile, keys k0 + ks*16 + 4 lg + r
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            float tm = -INFINITY;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (k0 + ks * 16 + lg * 4 + r >= p.Skv) s[t][ks][r] = -INFINITY;
+                    tm = fmaxf(tm, s[t][ks][r]);
+                }
+            tm = fmaxf(tm, __shfl_xor(tm, 16));
+            tm = fmaxf(tm, __shfl_xor(tm, 32));
+            const float mnew = fmaxf(mx[t], tm);               // finite: every tile holds at least one valid key
+            const float alpha = exp2f(mx[t] - mnew);
+            mx[t] = mnew;
+            float ps = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[t][ks][r] = exp2f(s[t][ks][r] - mnew); ps += s[t][ks][r]; }
+            lsum[t] = lsum[t] * alpha + ps;
+#pragma unroll
+            for (int c = 0; c < DT; ++c) o[t][c] *= alpha;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int c = 0; c < DT; ++c) {
+                float vf[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) vf[u] = Vs[(ks * 16 + lg * 4 + u) * LDK + c * 16 + li];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) o[t][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[u], s[t][ks][u], o[t][c], 0, 0, 0);
+            }
+        __syncthreads();
+    }
+    // O^T accumulator: lane (li = query, lg), register r = channel c*16 + 4 lg + r
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l = lsum[t];
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        const float inv = 1.0f / l;
+        const int q = q0 + t * 16 + li;
+        if (q >= p.Sq) continue;
+        float* Or = p.O + ((long long)nb * p.Sq + q) * p.ldo + head * d;
+#pragma unroll
+        for (int c = 0; c < DT; ++c) {
+            const int col = c * 16 + lg * 4;
+            if (col < d) *(floatx4*)(Or + col) = o[t][c] * inv;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------ GroupNorm: one block per (image, group)
 __global__ __launch_bounds__(256) void gn_f32_kernel(const float* X0, const float* X1, int C0, int C1, int HW, int groups, float eps,
                                                      const float* gamma, const float* beta, int silu, float* Y)
@@ -375,6 +559,77 @@ __global__ __launch_bounds__(256) void gn_f32_kernel(const float* X0, const floa
         float y = (at(i) - mean) * rstd * gamma[c] + beta[c];
         if (silu) y = y / (1.0f + expf(-y));
         Y[((long long)nb * HW + px) * C + c] = y;
+    }
+}
+
+// Row-streaming GroupNorm (the plain kernel above puts one block on each (image, group): 64 blocks at UNet batch 2).  Thread = one
+// float4 of channels, fixed for the thread's life, walking rows: coalesced row reads, per-channel sums in fp64 registers (single pass:
+// sum and sum of squares), combined per group through LDS in a fixed order.  Stage 1 leaves [image][slice][group] partials, stage 2
+// adds a group's slices in slice order, so the result does not depend on scheduling.
+struct GnF { const float* X0; const float* X1; int C0, C1, HW, groups, slices, rows_per_slice, rpi; float eps; const float* gamma; const float* beta;
+             int silu; float* Y; double* part; };
+__global__ void gn_f32_rows_stats_kernel(GnF p)
+{
+    extern __shared__ double sh[];                      // [rpi][C][2]
+    const int C = p.C0 + p.C1, C4 = C >> 2, cpg = C / p.groups;
+    const int tid = threadIdx.x, c4 = tid % C4, r0 = tid / C4, c = c4 * 4;
+    const int nb = blockIdx.y, sl = blockIdx.x;
+    const int row_end = min(p.HW, (sl + 1) * p.rows_per_slice);
+    const bool first = c < p.C0;
+    const float* src = first ? p.X0 + (long long)nb * p.HW * p.C0 + c : p.X1 + (long long)nb * p.HW * p.C1 + (c - p.C0);
+    const int ld = first ? p.C0 : p.C1;
+    double sm[4] = {0, 0, 0, 0}, sq[4] = {0, 0, 0, 0};
+    for (int r = sl * p.rows_per_slice + r0; r < row_end; r += p.rpi) {
+        const floatx4 v = *(const floatx4*)(src + (long long)r * ld);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const double x = v[j]; sm[j] += x; sq[j] = fma(x, x, sq[j]); }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { sh[((size_t)r0 * C + c + j) * 2] = sm[j]; sh[((size_t)r0 * C + c + j) * 2 + 1] = sq[j]; }
+    __syncthreads();
+    if (tid < p.groups) {
+        double a = 0, b = 0;
+        for (int r = 0; r < p.rpi; ++r)
+            for (int k = 0; k < cpg; ++k) { a += sh[((size_t)r * C + tid * cpg + k) * 2]; b += sh[((size_t)r * C + tid * cpg + k) * 2 + 1]; }
+        double* o = p.part + (((size_t)nb * p.slices + sl) * p.groups + tid) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+__global__ void gn_f32_rows_apply_kernel(GnF p)
+{
+    extern __shared__ double sh[];                      // reused as float [groups][2]: mean, rstd
+    float* st = (float*)sh;
+    const int C = p.C0 + p.C1, C4 = C >> 2, cpg = C / p.groups;
+    const int tid = threadIdx.x, c4 = tid % C4, r0 = tid / C4, c = c4 * 4;
+    const int nb = blockIdx.y, sl = blockIdx.x;
+    if (tid < p.groups) {
+        double a = 0, b = 0;
+        for (int k = 0; k < p.slices; ++k) {
+            const double* o = p.part + (((size_t)nb * p.slices + k) * p.groups + tid) * 2;
+            a += o[0]; b += o[1];
+        }
+        const double n = (double)p.HW * cpg, mean = a / n, var = fmax(b / n - mean * mean, 0.0);
+        st[tid * 2] = (float)mean;
+        st[tid * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    const bool first = c < p.C0;
+    const float* src = first ? p.X0 + (long long)nb * p.HW * p.C0 + c : p.X1 + (long long)nb * p.HW * p.C1 + (c - p.C0);
+    const int ld = first ? p.C0 : p.C1;
+    float mean[4], rs[4], ga[4], be[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int g = (c + j) / cpg; mean[j] = st[g * 2]; rs[j] = st[g * 2 + 1]; ga[j] = p.gamma[c + j]; be[j] = p.beta[c + j]; }
+    const int row_end = min(p.HW, (sl + 1) * p.rows_per_slice);
+    for (int r = sl * p.rows_per_slice + r0; r < row_end; r += p.rpi) {
+        const floatx4 v = *(const floatx4*)(src + (long long)r * ld);
+        floatx4 y;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float t = (v[j] - mean[j]) * rs[j] * ga[j] + be[j];
+            if (p.silu) t = t / (1.0f + expf(-t));
+            y[j] = t;
+        }
+        *(floatx4*)(p.Y + ((long long)nb * p.HW + r) * C + c) = y;
     }
 }
 
@@ -464,11 +719,36 @@ void f32_launch_gemm(const LaunchCtx& ctx, const GemmArgs& a)
     static const int mfma_env = [] { const char* v = getenv("SDE_F32_MFMA"); return v ? atoi(v) : 1; }();   // 0: plain FMA kernel everywhere
     const bool mfma = mfma_env && !ctx.force_naive && a.K % 16 == 0 && a.C0 % 16 == 0 && a.C1 % 16 == 0 && (a.taps == 1 || ckk % 16 == 0) &&
                       a.lda0 % 4 == 0 && (!a.A1 || a.lda1 % 4 == 0) && al16(a.A0) && al16(a.A1) && al16(a.W) && a.sA % 4 == 0 && a.sW % 4 == 0;
-    if (!mfma) hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a.M, BM), cdiv(a.N, BN), a.batch), dim3(256), 0, ctx.stream, p);
-    else if ((long long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch >= 192)
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<128, 128>), dim3(cdiv(a.M, 128), cdiv(a.N, 128), a.batch), dim3(256), 0, ctx.stream, p);
-    else
-        hipLaunchKernelGGL((gemm_f32_mfma_kernel<64, 64>), dim3(cdiv(a.M, 64), cdiv(a.N, 64), a.batch), dim3(256), 0, ctx.stream, p);
+    p.splitk = 1; p.ws = nullptr;
+    if (!mfma) { hipLaunchKernelGGL(gemm_f32_kernel, dim3(cdiv(a.M, BM), cdiv(a.N, BN), a.batch), dim3(256), 0, ctx.stream, p); HIP_CHECK(hipGetLastError()); return; }
+    // tuning hooks: SDE_F32_TILE = 64 / 128 forces the block tile, SDE_F32_SPLITK = n the K split (where it applies)
+    static const int tile_env = [] { const char* v = getenv("SDE_F32_TILE"); return v ? atoi(v) : 0; }();
+    static const int sk_env = [] { const char* v = getenv("SDE_F32_SPLITK"); return v ? atoi(v) : 0; }();
+    // Few tiles, long K (UNet batch 2: the 8 x 8 level's 3x3 convs are 40 tiles of 720 slabs): split K so that ~3 blocks per CU exist;
+    // partial tiles through the split-K workspace, reduced in slice order.  The 128 x 128 tile (half the operand traffic per flop) is
+    // taken when, with its split, it still yields two blocks per CU; measured per shape in DESIGN.md section 4 (fp32 engine).
+    const int nk = a.K / 16;
+    const bool can_split = a.batch == 1 && ctx.splitk_ws && nk >= 32;
+    auto split_for = [&](long long tiles) {
+        int sk = 1;
+        if (can_split && tiles < 512) {
+            sk = sk_env ? sk_env : (int)std::min<long long>(cdiv(768, (int)tiles), 16);
+            sk = std::max(1, std::min(sk, nk / 16));
+            while (sk > 1 && (size_t)sk * a.M * a.N * sizeof(float) > ctx.splitk_ws_bytes) --sk;
+            if (sk > 1) sk = cdiv(nk, cdiv(nk, sk));               // no empty K range
+        }
+        return sk;
+    };
+    const long long t128 = (long long)cdiv(a.M, 128) * cdiv(a.N, 128) * a.batch, t64 = (long long)cdiv(a.M, 64) * cdiv(a.N, 64) * a.batch;
+    const int tile = tile_env ? tile_env : (t128 * split_for(t128) >= 512 ? 128 : 64);
+    const int sk = split_for(tile == 128 ? t128 : t64);
+    if (sk > 1) { p.splitk = sk; p.ws = ctx.splitk_ws; }
+    const dim3 grid(cdiv(a.M, tile), cdiv(a.N, tile), sk > 1 ? sk : a.batch);
+    if (tile == 128) hipLaunchKernelGGL((gemm_f32_mfma_kernel<128, 128>), grid, dim3(256), 0, ctx.stream, p);
+    else hipLaunchKernelGGL((gemm_f32_mfma_kernel<64, 64>), grid, dim3(256), 0, ctx.stream, p);
+    if (sk > 1)
+        hipLaunchKernelGGL(gemm_f32_splitk_reduce_kernel, dim3((unsigned)std::min<long long>(cdiv64((long long)a.M * a.N, 256), 2048)), dim3(256), 0,
+                           ctx.stream, p);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -485,7 +765,16 @@ void f32_launch_attention(const LaunchCtx& ctx, const AttnArgs& a)
     AttnF p{(const float*)a.Q, (const float*)a.K, (const float*)a.V, (float*)a.O, a.ldq, a.ldk, a.ldv, a.ldo, a.NB, a.heads, a.Sq, a.Skv, a.d, a.scale};
     ProfScope ps(ctx, "attn_f32", 4.0 * a.NB * a.heads * (double)a.Sq * a.Skv * a.d, 0);
     const long long total = (long long)a.NB * a.heads * a.Sq;
-    if (a.d <= 192) hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)cdiv64(total, 4)), dim3(256), 0, ctx.stream, p);
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    static const int mfma_env = [] { const char* v = getenv("SDE_F32_MFMA"); return v ? atoi(v) : 1; }();
+    const bool mfma = mfma_env && !ctx.force_naive && a.d % 4 == 0 && a.d <= 160 && a.Skv >= 1 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 &&
+                      a.ldo % 4 == 0 && al16(a.Q) && al16(a.K) && al16(a.V) && al16(a.O);
+    if (mfma) {
+        const dim3 grid((unsigned)((long long)a.NB * a.heads * cdiv(a.Sq, 128)));
+        if (a.d <= 48) hipLaunchKernelGGL(attn_f32_mfma_kernel<3>, grid, dim3(256), 0, ctx.stream, p);
+        else if (a.d <= 80) hipLaunchKernelGGL(attn_f32_mfma_kernel<5>, grid, dim3(256), 0, ctx.stream, p);
+        else hipLaunchKernelGGL(attn_f32_mfma_kernel<10>, grid, dim3(256), 0, ctx.stream, p);
+    } else if (a.d <= 192) hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)cdiv64(total, 4)), dim3(256), 0, ctx.stream, p);
     else {
         SDE_REQUIRE((size_t)a.d * 16 <= 64 * 1024, SDE_ERR_INVALID_ARGUMENT, "fp32 attention: head too wide");
         hipLaunchKernelGGL(attn_f32_wide_kernel, dim3((unsigned)cdiv64(total, 4)), dim3(256), (size_t)a.d * 16, ctx.stream, p);
@@ -498,6 +787,25 @@ void f32_launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)
     const int C = a.C0 + a.C1;
     SDE_REQUIRE(C % a.groups == 0, SDE_ERR_INVALID_ARGUMENT, "groupnorm: C must be a multiple of the group count");
     ProfScope ps(ctx, "groupnorm_f32", 0, 16.0 * a.NB * a.HW * C);
+    const int C4 = C / 4;
+    auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
+    if (!ctx.force_naive && C % 4 == 0 && a.C0 % 4 == 0 && C4 <= 1024 && a.groups <= 64 && a.ws && al16(a.X0) && al16(a.X1) && al16(a.Y) &&
+        ((uintptr_t)a.ws & 7) == 0) {
+        GnF g;
+        g.rpi = C4 >= 256 ? 1 : 256 / C4;
+        const int threads = g.rpi * C4;
+        g.slices = std::max(1, std::min(64, a.HW / (g.rpi * 4)));          // >= 4 rows per thread, <= 64 slices (groupnorm_ws_floats)
+        g.rows_per_slice = cdiv(a.HW, g.slices);
+        g.slices = cdiv(a.HW, g.rows_per_slice);
+        g.X0 = (const float*)a.X0; g.X1 = (const float*)a.X1; g.C0 = a.C0; g.C1 = a.C1; g.HW = a.HW; g.groups = a.groups; g.eps = a.eps;
+        g.gamma = a.gamma; g.beta = a.beta; g.silu = a.silu ? 1 : 0; g.Y = (float*)a.Y; g.part = (double*)a.ws;
+        const size_t lds = (size_t)g.rpi * C * 2 * sizeof(double);         // <= 16 * C bytes * rpi: 64 KB at C = 4096
+        allow_dynamic_lds((const void*)gn_f32_rows_stats_kernel, 64 * 1024);
+        hipLaunchKernelGGL(gn_f32_rows_stats_kernel, dim3(g.slices, a.NB), dim3(threads), lds, ctx.stream, g);
+        hipLaunchKernelGGL(gn_f32_rows_apply_kernel, dim3(g.slices, a.NB), dim3(threads), 64 * 2 * sizeof(double), ctx.stream, g);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     hipLaunchKernelGGL(gn_f32_kernel, dim3(a.groups, a.NB), dim3(256), 0, ctx.stream, (const float*)a.X0, (const float*)a.X1, a.C0, a.C1, a.HW,
                        a.groups, a.eps, a.gamma, a.beta, a.silu ? 1 : 0, (float*)a.Y);
     HIP_CHECK(hipGetLastError());

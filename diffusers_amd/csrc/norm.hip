@@ -284,7 +284,8 @@ size_t groupnorm_ws_floats(int NB, int C, int HW)
 {
     int TPP, OPT, PR, ppc, nchunks;
     gn_geometry(C, HW, TPP, OPT, PR, ppc, nchunks);
-    return (size_t)NB * nchunks * 64 * 2;
+    // fp32 engine (f32path.hip): [NB][<= 64 slices][<= 64 groups][2] doubles
+    return std::max((size_t)NB * nchunks * 64 * 2, (size_t)NB * 64 * 64 * 4);
 }
 
 void launch_groupnorm(const LaunchCtx& ctx, const GroupNormArgs& a)

@@ -26,7 +26,7 @@ from .schedulers import DiffusionScheduler
 class StableDiffusionOptions:
     """pipelines/stable_diffusion/mod.rs:35-38 — here the only device choice is the MI355X ordinal."""
     device_id: int = 0
-    dtype: str = "f16"          # engine precision: "f16" (MFMA kernels, benchmarked) or "f32" (the reference's own precision, plain kernels)
+    dtype: str = "f16"          # engine precision: "f16" (MFMA kernels, benchmarked) or "f32" (the reference's own precision, fp32 MFMA tiles, ~8x slower)
     force_naive: bool = False
     num_heads_override: int = 0
 

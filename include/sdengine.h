@@ -50,7 +50,7 @@ typedef enum sde_dtype { SDE_F16 = 0, SDE_BF16 = 1, SDE_F32 = 2 } sde_dtype;
 typedef struct sde_engine_opts {
     int device_id;       /* HIP device ordinal (the new "native MI355X(device_id)" DiffusionDevice, lib.rs:81-107) */
     int dtype;           /* sde_dtype: activation/weight storage inside the engine; I/O is always f32.  SDE_F16 (default): MFMA kernels,
-                          * fp32 accumulation, the benchmarked path.  SDE_F32: every tensor and every product in fp32 (plain kernels), the
+                          * fp32 accumulation, the benchmarked path.  SDE_F32: every tensor and every product in fp32 (v_mfma_f32_16x16x4_f32 tiles, f32path.hip), the
                           * precision of the reference's own graphs (sd2pyke.py:86,120-125); bar 1e-4.  SDE_BF16: not implemented (refused).
                           * Limit of SDE_F16: its 1e-2 bar assumes every GroupNorm group holds >= 8 values (channels per group x H x W at the
                           * deepest level).  SD v1.x / v2.x meet that from 16 x 16 pixel images on (40 channels per group at the deepest level);
@@ -308,7 +308,8 @@ sde_status sde_synchronize(sde_engine* e);
 
 /* Kernel-level test hooks: run ONE contraction through the MFMA path (naive=0) or the plain path
  * (naive=1; 2 / 3 force the 256x320 / 256x160 kernels, 4 / 5 the 128x160 linear / halo 3x3 kernels, 6 the W-stationary streaming
- * kernel for short-K linears, gemm_ws.hip) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
+ * kernel for short-K linears, gemm_ws.hip; sde_test_conv and sde_test_attention also take 7 / 8 = the fp32 engine's MFMA-tile /
+ * plain kernels of f32path.hip, on unrounded fp32 operands) on host data.  conv: x NHWC f32 [NB,Hi,Wi,Cin], w OIHW f32, out NHWC f32.
  * upsample: 0 none, 1 nearest 2x before the conv, 2 nearest to (2*Hi-1) x (2*Wi-1) (the exported UNet's upsample to its skip
  * connection's size on odd latents), 3 = no upsample but the VAE encoder's downsampler window (pad (0,1,0,1), 3x3, stride 2, pad 0:
  * Ho = (Hi - 2) / 2 + 1).

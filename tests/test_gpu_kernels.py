@@ -419,3 +419,65 @@ def test_geglu_projection(engine, case, kern):
     a, g = y[:, :N // 2], y[:, N // 2:]
     ref = (a * (F.gelu(g, approximate="tanh") if tanh else F.gelu(g))).numpy()
     assert rel_l2(out, ref) < 2e-3, rel_l2(out, ref)
+
+
+# ---------------------------------------------------------------------------------------------- the fp32 engine's kernels (f32path.hip)
+F32_CONV_CASES = CONV_CASES + [
+    (2, 64, 64, 320, 320, 3, 1, 0),     # 128 x 128 tiles (>= 192 of them)
+    (2, 32, 32, 640, 1280, 1, 1, 0),    # 64 x 64 tiles, linear
+    (1, 10, 10, 48, 80, 3, 1, 0),       # 48 channels per tap: 16-float slabs inside a tap without the 64-channel chunking
+    (1, 9, 9, 20, 33, 1, 1, 0),         # K % 16 != 0: plain kernel on both paths
+]
+
+
+@pytest.mark.parametrize("case", F32_CONV_CASES)
+def test_f32_conv_mfma_vs_plain_vs_torch(engine, case):
+    """naive 7 / 8 = the fp32 engine's MFMA-tile / plain FMA kernel on unrounded fp32 operands; reference in fp64.  Bar 1e-5 rel-L2
+    (fp32 products and sums only; the engine-level bar is 1e-4)."""
+    NB, H, W, Cin, Cout, k, stride, ups = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    x = rng.standard_normal((NB, H, W, Cin)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    fast = run_conv(engine, 7, x, w, b, k, stride, ups)
+    plain = run_conv(engine, 8, x, w, b, k, stride, ups)
+    xt = torch.from_numpy(x).double().permute(0, 3, 1, 2)
+    if ups:
+        xt = F.interpolate(xt, scale_factor=2.0, mode="nearest")
+        if ups == 2:
+            xt = xt[:, :, :-1, :-1]
+    ref = F.conv2d(xt, torch.from_numpy(w).double(), torch.from_numpy(b).double(), stride=stride if k == 3 else 1,
+                   padding=1 if k == 3 else 0).permute(0, 2, 3, 1).numpy()
+    assert fast.shape == ref.shape
+    assert rel_l2(plain, ref) < 1e-5
+    assert rel_l2(fast, ref) < 1e-5
+
+
+@pytest.mark.parametrize("case", ATTN_CASES + [(2, 8, 4096, 4096, 40), (1, 1, 300, 300, 512)])
+def test_f32_attention_mfma_vs_plain_vs_torch(engine, case):
+    NB, heads, Sq, Skv, d = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    q = rng.standard_normal((NB, Sq, heads * d)).astype(np.float32)
+    k = rng.standard_normal((NB, Skv, heads * d)).astype(np.float32)
+    v = rng.standard_normal((NB, Skv, heads * d)).astype(np.float32)
+    fast = run_attn(engine, 7, q, k, v, heads)
+    def sp(t, S):
+        return torch.from_numpy(t).double().view(NB, S, heads, d).transpose(1, 2)
+    att = torch.softmax(sp(q, Sq) @ sp(k, Skv).transpose(-1, -2) * d ** -0.5, dim=-1)
+    ref = (att @ sp(v, Skv)).transpose(1, 2).reshape(NB, Sq, heads * d).numpy()
+    assert rel_l2(fast, ref) < 1e-5
+    if Sq * Skv <= 1 << 21:
+        assert rel_l2(run_attn(engine, 8, q, k, v, heads), ref) < 1e-5
+
+
+def test_f32_attention_softmax_rescale_branch(engine):
+    NB, heads, S, d = 1, 1, 256, 64
+    rng = np.random.default_rng(5)
+    q = rng.standard_normal((NB, S, d)).astype(np.float32)
+    k = rng.standard_normal((NB, S, d)).astype(np.float32)
+    v = rng.standard_normal((NB, S, d)).astype(np.float32)
+    k[0, 200] = q[0, 17] * 4.0
+    fast = run_attn(engine, 7, q, k, v, heads)
+    qt, kt, vt = (torch.from_numpy(t).double() for t in (q, k, v))
+    ref = (torch.softmax(qt @ kt.transpose(-1, -2) * d ** -0.5, dim=-1) @ vt).numpy()
+    assert rel_l2(fast, ref) < 1e-5 and np.abs(fast - ref).max() < 1e-4

@@ -7,7 +7,7 @@ from diffusers_amd import _lib, modelgen
 from diffusers_amd.pipeline import StableDiffusionPipeline
 
 NB = int(os.environ.get("NB", "16"))
-KERN = int(os.environ.get("MB_KERNEL", "0"))   # 0 heuristic, 2 / 3 force the 256x320 / 256x160 kernel (with SDE_SPLITK=n)
+KERN = int(os.environ.get("MB_KERNEL", "0"))   # 0 heuristic, 2 / 3 force the 256x320 / 256x160 kernel (with SDE_SPLITK=n); 7 / 8: the fp32 engine's MFMA / plain kernels
 CONVS = [  # H, Cin, Cout, k, stride, ups
     (64, 320, 320, 3, 1, 0), (64, 640, 320, 3, 1, 0), (32, 640, 640, 3, 1, 0), (32, 1280, 640, 3, 1, 0), (16, 1280, 1280, 3, 1, 0),
     (16, 2560, 1280, 3, 1, 0), (8, 1280, 1280, 3, 1, 0), (8, 2560, 1280, 3, 1, 0), (32, 320, 320, 3, 1, 1), (64, 320, 320, 3, 2, 0),
@@ -33,7 +33,7 @@ def main():
     rng = np.random.default_rng(0)
     reps = 4
     only = os.environ.get("MB_ONLY", "")
-    convs = VAE if only == "vae" else [c for c in CONVS if not only or (only == "small" and NB * c[0] * c[0] <= 4096) or (only == "big" and NB * c[0] * c[0] > 4096)
+    convs = VAE if only == "vae" else [c for c in CONVS if not only or only == "convs" or (only == "small" and NB * c[0] * c[0] <= 4096) or (only == "big" and NB * c[0] * c[0] > 4096)
              or (only == "c64" and c[0] == 64 and c[3] == 3 and c[4] == 1) or (only == "k64" and c[1] == 64) or (only == "wide" and c[3] == 1 and c[2] >= 960) or (only == "lin16" and c[0] == 16 and c[3] == 1) or (only == "lin64" and c[0] == 64 and c[3] == 1 and c[1] >= 320) or (only == "c32" and c[0] == 32 and c[3] == 3 and c[5] == 0)]
     for (H, Cin, Cout, k, stride, ups) in convs:
         x = rng.standard_normal((NB, H, H, Cin), dtype=np.float32)
@@ -45,7 +45,7 @@ def main():
         p.profile_reset(); p.profile(True)
         for _ in range(reps):
             _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data, out.size))
-        st = [s for s in p.profile_get() if "mfma" in s["name"]]
+        st = [s for s in p.profile_get() if "mfma" in s["name"] or "_f32" in s["name"]]
         p.profile(False)
         for s in st:
             us = s["total_ms"] / s["launches"] * 1e3
@@ -55,10 +55,10 @@ def main():
         kk = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
         v = rng.standard_normal((NB, Skv, heads * dd), dtype=np.float32)
         out = np.empty_like(q)
-        _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
+        _lib.check(L.sde_test_attention(p._h, KERN if KERN >= 7 else 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
         p.profile_reset(); p.profile(True)
         for _ in range(reps):
-            _lib.check(L.sde_test_attention(p._h, 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
+            _lib.check(L.sde_test_attention(p._h, KERN if KERN >= 7 else 0, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
         st = [s for s in p.profile_get() if "attn" in s["name"]]
         p.profile(False)
         for s in st:
