@@ -45,7 +45,7 @@ def main():
         p.profile_reset(); p.profile(True)
         for _ in range(reps):
             _lib.check(L.sde_test_conv(p._h, KERN, x.ctypes.data, NB, H, H, Cin, w.ctypes.data, None, Cout, k, stride, ups, out.ctypes.data, out.size))
-        st = [s for s in p.profile_get() if "mfma" in s["name"] or "_f32" in s["name"]]
+        st = [s for s in p.profile_get() if "mfma" in s["name"] or s["name"] in ("conv3x3_f32", "gemm_f32")]
         p.profile(False)
         for s in st:
             us = s["total_ms"] / s["launches"] * 1e3

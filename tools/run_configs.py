@@ -5,6 +5,7 @@ line per config: wall time, images/s, UNet it/s.  Synthetic weights and embeddin
     python tools/run_configs.py [--only 2,4,5] [--out profiles/r1_configs.json]
 
 configs (1-based, as in BASELINE.json):
+  1  SD1.5 512x512, Euler 20 steps, CFG 7.5, batch 1, fp32 ENGINE (configs[0], the reference's CPU-runnable case; --only 1,...)
   2  SD1.5 512x512, DPM++ 30 steps, CFG 7.5, batch 8                      (the bench.py workload)
   3  SD1.5 512x512, Euler-a 30 steps, micro-batch 8 of the 256 prompts    (one rank's share; sharding is bench.py --gpus N)
   4  SD2.1 768x768 v-prediction, DDIM "50 steps" (49 UNet calls, reference quirk), batch 4, heads of d=64, linear projections
@@ -36,6 +37,7 @@ def model_dir(kind):
 
 
 CONFIGS = {
+    1: dict(model="sd15", H=512, W=512, B=1, S=77, D=768, sched="euler", steps=20, guidance=7.5, pred=None, dtype="f32"),   # configs[0]: the CPU-runnable case, here on the fp32 ENGINE
     2: dict(model="sd15", H=512, W=512, B=8, S=77, D=768, sched="dpmpp", steps=30, guidance=7.5, pred=None),
     3: dict(model="sd15", H=512, W=512, B=8, S=77, D=768, sched="euler_a", steps=30, guidance=7.5, pred=None),
     4: dict(model="sd21", H=768, W=768, B=4, S=77, D=1024, sched="ddim", steps=50, guidance=7.5, pred="v"),
@@ -50,18 +52,19 @@ def main():
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     from diffusers_amd import schedulers as N
-    from diffusers_amd.pipeline import StableDiffusionPipeline, StableDiffusionTxt2ImgOptions
+    from diffusers_amd.pipeline import StableDiffusionOptions, StableDiffusionPipeline, StableDiffusionTxt2ImgOptions
     dev = torch.device("cuda", 0)
     results = []
     pipes = {}
     for idx in [int(x) for x in args.only.split(",")]:
         c = CONFIGS[idx]
-        if c["model"] not in pipes:
+        key = (c["model"], c.get("dtype", "f16"))
+        if key not in pipes:
             for p in pipes.values():
                 p.close()
             pipes.clear()
-            pipes[c["model"]] = StableDiffusionPipeline(model_dir(c["model"]))
-        pipe = pipes[c["model"]]
+            pipes[key] = StableDiffusionPipeline(model_dir(c["model"]), StableDiffusionOptions(dtype=key[1]))
+        pipe = pipes[key]
         B, S, D, H, W = c["B"], c["S"], c["D"], c["H"], c["W"]
         g = torch.Generator(device="cpu").manual_seed(idx)
         ehs = (torch.randn(2 * B, S, D, generator=g) * 0.5).to(dev)
@@ -95,7 +98,7 @@ def main():
         print(json.dumps(line), flush=True)
         results.append(line)
     if args.out:
-        json.dump({"device": torch.cuda.get_device_name(0), "note": "one MI355X, fp16 engine, synthetic weights; best of "
+        json.dump({"device": torch.cuda.get_device_name(0), "note": "one MI355X, fp16 engine (config 1: fp32 engine), synthetic weights; best of "
                    f"{args.repeat} after one warm-up pass; inputs resident in HBM", "results": results}, open(args.out, "w"), indent=1)
 
 
