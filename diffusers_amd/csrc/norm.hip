@@ -412,6 +412,88 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const half_t* X, half_t*
     }
 }
 
+// Lane-dense LayerNorm for the UNet's widths (C = 320 / 640 / 1280 = 40 L octets... i.e. L = 8 / 16 / 32 lanes per row, five 16-byte chunks
+// per lane): the kernels above put one chunk on each lane, which at C = 320 leaves 24 of 64 lanes idle in every memory instruction.
+// Here a wave normalises 64 / L rows at a time with every lane busy (lane l of a row's group holds chunks l, l + L, .. l + 4L, so the
+// group's loads of one instruction are L x 16 contiguous bytes), keeps its gamma / beta slice in registers and walks a strided list
+// of row groups.  y = LN(A + B + Cc) with the sum formed in fp32 in the given order (B, Cc optional); exact two-pass variance.
+template <int L, int NIN>
+__global__ __launch_bounds__(256) void layernorm_lanes_kernel(const half_t* A, const half_t* B, const half_t* Cc, half_t* Y, int rows, int C,
+                                                              const float* gamma, const float* beta, float eps)
+{
+    constexpr int RPW = 64 / L;
+    const int lane = threadIdx.x & 63, l = lane % L, sub = lane / L;
+    float g[5][8], bt[5][8];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const float4 g0 = *(const float4*)(gamma + (l + L * i) * 8), g1 = *(const float4*)(gamma + (l + L * i) * 8 + 4);
+        const float4 b0 = *(const float4*)(beta + (l + L * i) * 8), b1 = *(const float4*)(beta + (l + L * i) * 8 + 4);
+        g[i][0] = g0.x; g[i][1] = g0.y; g[i][2] = g0.z; g[i][3] = g0.w; g[i][4] = g1.x; g[i][5] = g1.y; g[i][6] = g1.z; g[i][7] = g1.w;
+        bt[i][0] = b0.x; bt[i][1] = b0.y; bt[i][2] = b0.z; bt[i][3] = b0.w; bt[i][4] = b1.x; bt[i][5] = b1.y; bt[i][6] = b1.z; bt[i][7] = b1.w;
+    }
+    const int ngroups = (rows + RPW - 1) / RPW, stride = gridDim.x * (blockDim.x >> 6);
+    const float invC = 1.0f / (float)C;
+    for (int grp = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); grp < ngroups; grp += stride) {
+        const int row = grp * RPW + sub;
+        const long long off = (long long)min(row, rows - 1) * C + l * 8;
+        half8 a[5], b[NIN > 1 ? 5 : 1], c[NIN > 2 ? 5 : 1];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            a[i] = *(const half8*)(A + off + L * 8 * i);
+            if constexpr (NIN > 1) b[i] = *(const half8*)(B + off + L * 8 * i);
+            if constexpr (NIN > 2) c[i] = *(const half8*)(Cc + off + L * 8 * i);
+        }
+        float v[5][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = (float)a[i][j];
+                if constexpr (NIN > 1) x += (float)b[i][j];
+                if constexpr (NIN > 2) x += (float)c[i][j];
+                v[i][j] = x;
+                sum += x;
+            }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float mean = sum * invC;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq = fmaf(d, d, sq); }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        const float rstd = rsqrtf(sq * invC + eps);
+        if (row < rows) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                half8 out;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) out[j] = (half_t)((v[i][j] - mean) * rstd * g[i][j] + bt[i][j]);
+                *(half8*)(Y + off + L * 8 * i) = out;
+            }
+        }
+    }
+}
+// true if launched
+static bool launch_layernorm_lanes(const LaunchCtx& ctx, const half_t* A, const half_t* B, const half_t* Cc, half_t* Y, int rows, int C,
+                                   const float* gamma, const float* beta, float eps)
+{
+    static const int env = getenv("SDE_LN_LANES") ? atoi(getenv("SDE_LN_LANES")) : 1;   // tuning hook: 0 = the one-chunk-per-lane kernels
+    const int L = C / 40;
+    if (!env || C % 40 || (L != 8 && L != 16 && L != 32) || rows < 1024 || (Cc && !B)) return false;
+    const int nin = Cc ? 3 : (B ? 2 : 1), rpw = 64 / L;
+    const int grid = std::max(1, std::min(cdiv(rows, rpw * 4 * 2), 2048));      // two or more row groups per wave
+#define LNL(L_, N_) hipLaunchKernelGGL((layernorm_lanes_kernel<L_, N_>), dim3(grid), dim3(256), 0, ctx.stream, A, B, Cc, Y, rows, C, gamma, beta, eps)
+#define LNL_N(L_) do { if (nin == 1) LNL(L_, 1); else if (nin == 2) LNL(L_, 2); else LNL(L_, 3); } while (0)
+    if (L == 8) LNL_N(8); else if (L == 16) LNL_N(16); else LNL_N(32);
+#undef LNL_N
+#undef LNL
+    return true;
+}
+
 void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows, int C, const float* gamma, const float* beta, float eps)
 {
     if (ctx.f32) { f32_launch_layernorm_sum(ctx, nullptr, X, nullptr, nullptr, Y, rows, C, gamma, beta, eps); return; }
@@ -419,6 +501,7 @@ void launch_layernorm(const LaunchCtx& ctx, const half_t* X, half_t* Y, int rows
     char nm_l[48] = "layernorm";
     if (getenv("SDE_PROF_SHAPES") && atoi(getenv("SDE_PROF_SHAPES"))) snprintf(nm_l, sizeof(nm_l), "ln M%d C%d", rows, C);
     ProfScope ps(ctx, nm_l, 0, 4.0 * rows * C);
+    if (launch_layernorm_lanes(ctx, X, nullptr, nullptr, Y, rows, C, gamma, beta, eps)) { HIP_CHECK(hipGetLastError()); return; }
     const int noct = cdiv(C / 8, 64);
     const dim3 block(256);
 #define LN_LAUNCH(O, R) hipLaunchKernelGGL((layernorm_kernel<O, R>), dim3(cdiv(rows, 4 * R)), block, 0, ctx.stream, X, Y, rows, C, gamma, beta, eps)
@@ -535,6 +618,7 @@ static void launch_layernorm_sum_impl(const LaunchCtx& ctx, const float* S32, co
 {
     SDE_REQUIRE(C % 8 == 0 && C / 8 <= 64 * LN_MAX_OCT, SDE_ERR_INVALID_ARGUMENT, "layernorm: unsupported width");
     ProfScope ps(ctx, "layernorm_sum", 0, (double)rows * C * ((S32 ? 4.0 : 0.0) + (A ? 2.0 : 0.0) + (B ? 2.0 : 0.0) + (Cc ? 2.0 : 0.0) + (S32_out ? 4.0 : 0.0) + 2.0));
+    if (!S32 && !S32_out && A && launch_layernorm_lanes(ctx, A, B, Cc, Y, rows, C, gamma, beta, eps)) { HIP_CHECK(hipGetLastError()); return; }
     const int noct = cdiv(C / 8, 64);
     const dim3 block(256);
 #define LN_LAUNCH(O, R) hipLaunchKernelGGL((layernorm_sum_kernel<O, R>), dim3(cdiv(rows, 4 * R)), block, 0, ctx.stream, S32, A, B, Cc, S32_out, Y, rows, C, gamma, beta, eps)
