@@ -1,7 +1,8 @@
 """GPU: short runs of the randomised parity sweeps (tools/fuzz_kernels.py, tools/fuzz_models.py): random conv / GEMM / attention
 shapes through the C ABI test hooks against torch fp32, and random small UNet / VAE architectures (raw and optimizer-fused
-dialects, odd latent sizes) against the CPU oracle.  The long sweeps are run by hand (2,840 kernel cases, 112 models and 78 whole-loop
-runs at the time of writing, no miss)."""
+dialects, odd latent sizes) against the CPU oracle.  The long sweeps are run by hand (round 2: 2,840 kernel cases, 112 models and 78
+whole-loop runs; round 3, with the W-stationary kernel, the GEGLU / residual hooks and the fp32 engine's MFMA kernels in the draw:
+1,400 kernel cases, 40 + 25 (fp32 engine) models, 30 whole-loop runs; no miss)."""
 import os
 import runpy
 import sys

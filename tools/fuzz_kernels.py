@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep of the contraction kernels through the C ABI test hooks (sde_test_conv / sde_test_attention) against a
-torch fp32 reference on fp16-rounded operands.  Shapes are drawn from the ranges the UNet / VAE produce (including odd spatial
+"""Randomised parity sweep of the contraction kernels through the C ABI test hooks (sde_test_conv / _conv_res / _geglu / _attention)
+against a torch reference on fp16-rounded operands (fp32 engine kernels, selector 7 / 8: fp64 on the unrounded operands, bar 2e-5).  Shapes are drawn from the ranges the UNet / VAE produce (including odd spatial
 sizes, ragged tiles, cropped upsampling, every kernel family via the `naive` selector).  Prints the worst cases; exit code 1 on a
 miss.  usage: python tools/fuzz_kernels.py [n_cases] [seed]"""
 import os
@@ -33,7 +33,47 @@ def main():
     rng = np.random.default_rng(seed)
     worst, bad = [], 0
     for it in range(n_cases):
-        if it % 3 != 2:
+        if it % 7 == 5:
+            # GEGLU projection hook: heuristic / plain / 256x320 / W-stationary kernel
+            M = int(rng.choice([int(rng.integers(1, 3000)), 256 * int(rng.integers(1, 12))]))
+            K = int(rng.choice([320, 320, 640, 64, 128]))
+            N = int(rng.choice([640, 2560, 320, 960, 1280]))
+            tanh = int(rng.integers(0, 2))
+            kern = int(rng.choice([0, 1, 2, 6, 6]))
+            x = rng.standard_normal((M, K)).astype(np.float32)
+            w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+            b = rng.standard_normal(N).astype(np.float32)
+            out = np.empty((M, N // 2), np.float32)
+            _lib.check(L.sde_test_geglu(pipe._h, kern, x.ctypes.data, M, K, w.ctypes.data, b.ctypes.data, N, tanh, out.ctypes.data, out.size))
+            y = torch.from_numpy(x).half().double() @ torch.from_numpy(w).half().double().T + torch.from_numpy(b).double()
+            a, g = y[:, :N // 2], y[:, N // 2:]
+            ref = (a * (F.gelu(g, approximate="tanh") if tanh else F.gelu(g))).numpy()
+            err, tag = rel_l2(out, ref), f"geglu kern={kern} M={M} K={K} N={N} tanh={tanh}"
+        elif it % 7 == 6:
+            # residual epilogue (plain and split-fp16) on every kernel family that has one; K = 320 linears reach the W-stationary kernel
+            k = int(rng.choice([1, 1, 3]))
+            cin = int(rng.choice([320, 320, 640, 128])) if k == 1 else int(rng.choice([64, 128, 320]))
+            cout = int(rng.choice([160, 320, 640, 480]))
+            H, W = (int(rng.choice([16, 32, 48, 64])), int(rng.choice([16, 32, 64]))) if rng.random() < 0.6 else (int(rng.integers(1, 40)), int(rng.integers(1, 40)))
+            NB = int(rng.integers(1, 3))
+            split = int(rng.integers(0, 2))
+            kern = int(rng.choice([0, 2, 4, 5, 6, 6]))
+            x = rng.standard_normal((NB, H, W, cin)).astype(np.float32)
+            w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
+            b = rng.standard_normal(cout).astype(np.float32)
+            res = (rng.standard_normal((NB, H, W, cout)) * 3).astype(np.float32)
+            out = np.empty((NB, H, W, cout), np.float32)
+            _lib.check(L.sde_test_conv_res(pipe._h, kern, x.ctypes.data, NB, H, W, cin, w.ctypes.data, b.ctypes.data, cout, k, res.ctypes.data, split,
+                                           out.ctypes.data, out.size))
+            conv = F.conv2d(torch.from_numpy(x).half().double().permute(0, 3, 1, 2), torch.from_numpy(w).half().double(), torch.from_numpy(b).double(),
+                            stride=1, padding=k // 2).permute(0, 2, 3, 1).numpy()
+            ref = conv + (res.astype(np.float64) if split else torch.from_numpy(res).half().double().numpy())
+            err, tag = rel_l2(out, ref), f"conv_res kern={kern} split={split} NB={NB} {H}x{W} {cin}->{cout} k{k}"
+            if split:
+                err *= 3e-3 / 4e-5          # hi + lo carries ~22 bits: bar 4e-5, expressed on the common 3e-3 scale below
+            else:
+                err *= 3e-3 / 8e-4
+        elif it % 3 != 2:
             k = int(rng.choice([1, 3, 3]))
             cin = int(rng.choice([64, 128, 192, 320, 640, 24]))
             cout = int(rng.choice([160, 320, 128, 256, 480, 640, 4, 40]))
@@ -45,7 +85,9 @@ def main():
             ups = int(rng.choice([0, 0, 1, 2])) if (k == 3 and stride == 1) else 0
             if ups == 2 and (H < 2 or W < 2):
                 ups = 1
-            kern = int(rng.choice([0, 0, 2, 3, 4, 5, 5]))   # 4 / 5: the 128x160 linear and halo 3x3 kernels where they support the case
+            kern = int(rng.choice([0, 0, 2, 3, 4, 5, 5, 6, 7, 7, 8]))   # 4 / 5 / 6: the 128x160 linear, halo 3x3 and W-stationary kernels where they support the case; 7 / 8: fp32 engine
+            if kern == 6:
+                k, cin, stride, ups = 1, 320, 1, 0
             x = rng.standard_normal((NB, H, W, cin)).astype(np.float32)
             w = (rng.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32)
             b = rng.standard_normal(cout).astype(np.float32)
@@ -54,34 +96,43 @@ def main():
             out = np.empty((NB, Ho, Wo, cout), np.float32)
             _lib.check(L.sde_test_conv(pipe._h, kern, x.ctypes.data, NB, H, W, cin, w.ctypes.data, b.ctypes.data, cout, k, stride, ups,
                                        out.ctypes.data, out.size))
-            xt = torch.from_numpy(x).half().float().permute(0, 3, 1, 2)
+            f32k = kern >= 7
+            xt = (torch.from_numpy(x).double() if f32k else torch.from_numpy(x).half().float()).permute(0, 3, 1, 2)
             if ups:
                 xt = F.interpolate(xt, size=(Hv, Wv), mode="nearest")
-            ref = F.conv2d(xt, torch.from_numpy(w).half().float(), torch.from_numpy(b), stride=stride if k == 3 else 1,
+            wt = torch.from_numpy(w).double() if f32k else torch.from_numpy(w).half().float()
+            ref = F.conv2d(xt, wt, torch.from_numpy(b).to(wt.dtype), stride=stride if k == 3 else 1,
                            padding=1 if k == 3 else 0).permute(0, 2, 3, 1).numpy()
             err, tag = rel_l2(out, ref), f"conv kern={kern} NB={NB} {H}x{W} {cin}->{cout} k{k} s{stride} u{ups}"
+            if f32k:
+                err *= 3e-3 / 2e-5          # fp32 kernels: bar 2e-5
         else:
             dd = int(rng.choice([40, 64, 80, 160, 16, 48, 12]))
             heads = int(rng.integers(1, 9))
             Sq = int(rng.integers(1, 700))
             Skv = Sq if rng.random() < 0.5 else int(rng.choice([77, 152, 227, int(rng.integers(1, 300))]))
             NB = int(rng.integers(1, 3))
-            kern = int(rng.choice([0, 0, 1]))
+            kern = int(rng.choice([0, 0, 1, 7, 7, 8]))
+            if kern == 8 and Sq * Skv > 200000:
+                kern = 7
             q = rng.standard_normal((NB, Sq, heads * dd)).astype(np.float32)
             kk = rng.standard_normal((NB, Skv, heads * dd)).astype(np.float32)
             v = rng.standard_normal((NB, Skv, heads * dd)).astype(np.float32)
             out = np.empty_like(q)
             _lib.check(L.sde_test_attention(pipe._h, kern, q.ctypes.data, kk.ctypes.data, v.ctypes.data, NB, heads, Sq, Skv, dd, out.ctypes.data, out.size))
-            sp = lambda t, S: torch.from_numpy(t).half().float().reshape(NB, S, heads, dd).permute(0, 2, 1, 3)
+            f32k = kern >= 7
+            sp = lambda t, S: (torch.from_numpy(t).double() if f32k else torch.from_numpy(t).half().float()).reshape(NB, S, heads, dd).permute(0, 2, 1, 3)
             ref = F.scaled_dot_product_attention(sp(q, Sq), sp(kk, Skv), sp(v, Skv)).permute(0, 2, 1, 3).reshape(NB, Sq, heads * dd).numpy()
             err, tag = rel_l2(out, ref), f"attn kern={kern} NB={NB} heads={heads} Sq={Sq} Skv={Skv} d={dd}"
+            if f32k:
+                err *= 3e-3 / 2e-5
         worst.append((err, tag))
         if not np.isfinite(err) or err > 3e-3:
             bad += 1
             print("MISS", err, tag, flush=True)
     worst.sort(reverse=True)
     for e, t in worst[:8]:
-        print(f"{e:.2e}  {t}")
+        print(f"{e:.2e}  {t}   (errors of the tighter-bar families are scaled to the common 3e-3 bar)")
     print(f"{n_cases} cases, {bad} misses")
     pipe.close()
     sys.exit(1 if bad else 0)
