@@ -121,6 +121,13 @@ def rocprof_symbol(cls):
     return ROCPROF_SYMBOL.get(cls) or re.sub(r"^attn_mfma<(\d+),(\d+)>$", r"attn_mfma_kernel<\1, \2, ONES, FOLD>", cls)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def spawn_ranks(n, argv):
     """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) as children and relay rank 0's JSON line.
     Runs before this process has initialised the GPU (children are fresh interpreters, not forks of a GPU process).
@@ -232,7 +239,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    # SDE_BENCH_FORCE_DIST=1: initialise the process group even for ONE rank, so that a one-GPU box executes the RCCL path of this file
+    # (communicator set-up, barrier, the max / sum all-reduces of job_throughput) -- the only part of the N > 1 launch it can run
+    force_dist = world == 1 and os.environ.get("SDE_BENCH_FORCE_DIST") == "1" and not args.rehearse
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dist:
         import torch.distributed as dist
         # SDE_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks then share devices)
         backend = "gloo" if args.rehearse else os.environ.get("SDE_BENCH_BACKEND", "nccl")
