@@ -409,10 +409,13 @@ def main():
         tot = sum(s["total_ms"] for s in stats) or 1.0
         for s in sorted(stats, key=lambda s: -s["total_ms"]):
             avg = s["total_ms"] / max(1, s["launches"])
+            tf = s["flops"] / (s["total_ms"] * 1e-3) / 1e12 if s["flops"] and s["total_ms"] else None
+            gb = s["bytes"] / (s["total_ms"] * 1e-3) / 1e9 if s["bytes"] and s["total_ms"] else None
+            # each class against BOTH roofs (algorithmic flops and bytes): `bound` is the roof it sits closer to
+            fm, fh = (tf / PEAK_TFLOPS_F16 if tf else 0.0), (gb / PEAK_HBM_GBS if gb else 0.0)
             kernel_table.append(dict(name=s["name"], launches=s["launches"], total_ms=round(s["total_ms"], 3), avg_us=round(avg * 1e3, 2),
-                                     share=round(s["total_ms"] / tot, 4),
-                                     tflops=round(s["flops"] / (s["total_ms"] * 1e-3) / 1e12, 1) if s["flops"] and s["total_ms"] else None,
-                                     gbs=round(s["bytes"] / (s["total_ms"] * 1e-3) / 1e9, 1) if s["bytes"] and s["total_ms"] else None))
+                                     share=round(s["total_ms"] / tot, 4), tflops=round(tf, 1) if tf else None, gbs=round(gb, 1) if gb else None,
+                                     bound="mfma" if fm >= fh else "hbm", roof_frac=round(max(fm, fh), 3)))
         # dominant kernel = the rocprof symbol with the largest summed time (classes that share a symbol are merged)
         by_sym = {}
         for st in stats:
