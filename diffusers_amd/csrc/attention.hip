@@ -48,21 +48,23 @@ struct AttnDev {
 // DMA (head dims 33..64: SD1.x d=40, SD2.x d=64): K/V tiles go global -> LDS directly (buffer_load ... lds) into a 3-deep ring,
 //  two tiles ahead, retired with a counted vmcnt; no staging registers, no ds_write.  Pad chunks (zeros, the FOLD / ONES
 //  constants) are written once per ring slot and never touched again: the DMA lanes that would cover them are masked off.
-template <int DQK, int DVT>
+// RING: depth of the LDS-DMA ring (DMA variants only).  3 = loads two tiles ahead, 2 blocks per CU by the 160-register budget the
+// kernel then takes; 2 = one tile ahead, 28.7 KB per block and a 128-register budget: FOUR blocks per CU.
+template <int DQK, int DVT, int RING = 3>
 struct AttnLayout {
     static constexpr bool KSWZ = DQK == 64;
     static constexpr int KROW = KSWZ ? DQK : DQK + 8;                     // K-tile row (elements)
     static constexpr int VROW = DVT > 5 ? DVT * 16 + 8 : ((DVT & 1) ? DVT * 16 : DVT * 16 + 16);     // V-tile row (elements); wide heads: measured no gain
     static constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
     static constexpr bool DMA = PREFETCH && DQK == 64;
-    static constexpr int NBUF = DMA ? 3 : (PREFETCH ? 2 : 1);  // the register-staged prefetching variants double-buffer: one barrier per tile
+    static constexpr int NBUF = DMA ? RING : (PREFETCH ? 2 : 1);  // the register-staged prefetching variants double-buffer: one barrier per tile
     static constexpr int SMEM_BYTES = NBUF * 64 * (KROW + VROW) * 2;
 };
 
-template <int DQK, int DVT, bool ONES, bool FOLD>
-__global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(AttnDev p)
+template <int DQK, int DVT, bool ONES, bool FOLD, int RING = 3>
+__global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void attn_mfma_kernel(AttnDev p)
 {
-    using L = AttnLayout<DQK, DVT>;
+    using L = AttnLayout<DQK, DVT, RING>;
     constexpr bool KSWZ = L::KSWZ, PREFETCH = L::PREFETCH, DMA = L::DMA;
     constexpr int KROW = L::KROW, VROW = L::VROW, NBUF = L::NBUF;
     constexpr int KS = DQK / 32;         // k-steps of the score product
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
         __syncthreads();
         const int ntile = (p.Skv + 63) >> 6;
         issue_tile(0, 0);
-        if (ntile > 1) issue_tile(64, 1);
+        if (RING == 3 && ntile > 1) issue_tile(64, 1);
         int slot = 0;
         const int nfull = p.Skv >> 6;
         // Full tiles.  The inner loop is the common path only: scores, exponentials, P.V, with O accumulated in place.  A tile whose
@@ -480,17 +482,18 @@ __global__ __launch_bounds__(256, (DVT <= 6 ? 2 : 1)) void attn_mfma_kernel(Attn
             for (; t < nfull; ++t) {
                 // this wave's pieces of tile t have landed (tile t+1's NKI+NVI pieces may stay in flight); the barrier then makes the
                 // whole tile visible and tells everyone that slot (t+2)%3 == (t-1)%3 is no longer read
-                if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKI + NVI) : "memory");
+                if (RING == 3 && t + 1 < ntile) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKI + NVI) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (t + 2 < ntile) issue_tile((t + 2) * 64, slot == 0 ? 2 : slot - 1);
+                if constexpr (RING == 3) { if (t + 2 < ntile) issue_tile((t + 2) * 64, slot == 0 ? 2 : slot - 1); }
+                else { if (t + 1 < ntile) issue_tile((t + 1) * 64, slot ^ 1); }      // the other slot was last read in tile t-1: the barrier above has passed it
                 if (tile(t * 64, slot, std::false_type{}, std::integral_constant<int, 1>{})) { unfinished = true; break; }
-                slot = slot == 2 ? 0 : slot + 1;
+                slot = RING == 3 ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
             }
             if (!unfinished) break;
             (void)tile(t * 64, slot, std::false_type{}, std::integral_constant<int, 2>{});
-            slot = slot == 2 ? 0 : slot + 1;
+            slot = RING == 3 ? (slot == 2 ? 0 : slot + 1) : (slot ^ 1);
             ++t;
         }
         if (nfull < ntile) {   // the ragged last tile, peeled: with both tile bodies inside the loop the compiler kept every loop-carried
@@ -621,6 +624,16 @@ template <int DQK, int DVT>
 static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
 {
     dim3 grid(cdiv(p.Sq, 128), p.heads, p.NB);
+    if constexpr (DQK == 64 && DVT == 3) {
+        // d = 40 (SD v1.x): the two-slot ring, four blocks per CU (tuning hook SDE_ATTN_RING=3: the three-slot ring, two to three per CU)
+        static const int ring_env = getenv("SDE_ATTN_RING") ? atoi(getenv("SDE_ATTN_RING")) : 2;
+        static const int fold_env2 = getenv("SDE_ATTN_FOLD") ? atoi(getenv("SDE_ATTN_FOLD")) : 1;
+        // short key ranges (cross-attention: two tiles) keep the deeper ring: with one tile of look-ahead their few loads are all exposed (47.6 -> 54 us measured)
+        if (ring_env == 2 && fold_env2 && p.d < DQK && p.d < DVT * 16 && p.Skv >= 512) {
+            hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, true, 2>), grid, dim3(256), (AttnLayout<DQK, DVT, 2>::SMEM_BYTES), ctx.stream, p);
+            return;
+        }
+    }
     constexpr int smem = AttnLayout<DQK, DVT>::SMEM_BYTES;
     static const int fold_env = getenv("SDE_ATTN_FOLD") ? atoi(getenv("SDE_ATTN_FOLD")) : 1;   // tuning hook
     const bool fold = fold_env && p.d < DQK && DVT <= 4;    // needs two spare score-product columns; wider heads run out of VGPRs (measured slower)
