@@ -10,6 +10,7 @@ from diffusers_amd.pipeline import StableDiffusionPipeline
 SHAPES = [  # M, K, N, kind (std | lo = split-fp16 residual and result | geglu)
     (65536, 320, 320, "std"), (65536, 320, 960, "std"), (65536, 640, 320, "lo"), (65536, 320, 2560, "geglu"),
     (16384, 640, 640, "std"), (16384, 640, 1920, "std"), (16384, 640, 5120, "geglu"), (16384, 640, 640, "lo"), (65536, 640, 320, "std"),
+    (4096, 1280, 3840, "std"), (4096, 1280, 1280, "std"), (16384, 2560, 640, "std"), (4096, 5120, 1280, "std"), (65536, 1280, 320, "std"),   # 9 .. 13
 ]
 
 
