@@ -61,7 +61,10 @@ struct AttnLayout {
     static constexpr int SMEM_BYTES = NBUF * 64 * (KROW + VROW) * 2;
 };
 
-template <int DQK, int DVT, bool ONES, bool FOLD, int RING = 3>
+// PERSIST (DMA variants, key range <= RING tiles: cross-attention): the block loads ALL of its head's K / V once, then walks query
+// blocks qb, qb + gridDim.x, .. with no block barrier in that loop -- the one-block-per-query-block form spent most of a 77-key launch
+// on per-block set-up (pad constants, the DMA round trip, two barriers) around two tiles of work.
+template <int DQK, int DVT, bool ONES, bool FOLD, int RING = 3, bool PERSIST = false>
 __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void attn_mfma_kernel(AttnDev p)
 {
     using L = AttnLayout<DQK, DVT, RING>;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
         const int hb = bid / per_head;
         head = hb % gridDim.y; nb = hb / gridDim.y;
     }
-    const int q0 = qb * 128 + wid * 32;
+    int q0 = qb * 128 + wid * 32;
     const int d = p.d;
     const float csl = p.scale_log2e;
 
@@ -99,19 +102,22 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
 
     // Q fragments (B operand): lane holds Q[q = q0 + 16*qt + fr][8*(4*ks+fg) .. +8]
     half8 qf[2][KS];
+    auto load_q = [&]() {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            int q = q0 + qt * 16 + fr, c = (ks * 4 + fg) * 8;
-            half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (q < p.Sq && c < d) v = *(const half8*)(Qb + (long long)q * p.ldq + c);
-            if (FOLD) {
+            for (int ks = 0; ks < KS; ++ks) {
+                int q = q0 + qt * 16 + fr, c = (ks * 4 + fg) * 8;
+                half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (q < p.Sq && c < d) v = *(const half8*)(Qb + (long long)q * p.ldq + c);
+                if (FOLD) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * csl);
+                    for (int j = 0; j < 8; ++j) v[j] = (half_t)((float)v[j] * csl);
+                }
+                qf[qt][ks] = v;
             }
-            qf[qt][ks] = v;
-        }
+    };
+    load_q();
     // FOLD: column d (chunk ks_e, lane group fg_e) of Q holds -M_hi, column d+1 -M_lo (M = running max, log2 units); zero until the first tile is done
     const int ks_e = d >> 5, fg_e = (d >> 3) & 3;
 
@@ -405,6 +411,31 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
             return false;
         }
     };
+    auto finish = [&]() {
+    // finish: o[dt][qt][r] <-> d index 16*dt + 4*fg + r, q = q0 + 16*qt + fr
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l;
+        if (ONES) l = __shfl(o[DVT - 1][qt][3], 48 + fr);   // row 16*DVT-1 of O^T lives in lane group 3, register 3
+        else {
+            l = lrow[qt];
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+        }
+        float inv = 1.0f / l;
+        int q = q0 + qt * 16 + fr;
+        if (q >= p.Sq) continue;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+            int c = dt * 16 + fg * 4;
+            if (c < d) {
+                half4 h = {(half_t)(o[dt][qt][0] * inv), (half_t)(o[dt][qt][1] * inv), (half_t)(o[dt][qt][2] * inv),
+                           (half_t)(o[dt][qt][3] * inv)};
+                *(half4*)(Ob + (long long)q * p.ldo + c) = h;
+            }
+        }
+    }
+    };
     using M0 = std::integral_constant<int, 0>;
 
     if constexpr (DMA) {
@@ -468,6 +499,27 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
         }
         __syncthreads();
         const int ntile = (p.Skv + 63) >> 6;
+        if constexpr (PERSIST) {
+            // every tile of this head into its own slot (launcher: ntile <= RING), one wait, one barrier -- then no barrier any more
+            for (int t = 0; t < ntile; ++t) issue_tile(t * 64, t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const int nfullp = p.Skv >> 6, nqb = (p.Sq + 127) >> 7;
+            for (int qbi = qb;;) {
+                for (int t = 0; t < nfullp; ++t) tile(t * 64, t, std::false_type{}, M0{});
+                if (nfullp < ntile) tile(nfullp * 64, nfullp, std::true_type{}, M0{});
+                finish();
+                qbi += (int)gridDim.x;
+                if (qbi >= nqb) break;
+                q0 = qbi * 128 + wid * 32;
+                load_q();
+#pragma unroll
+                for (int a = 0; a < DVT; ++a) { o[a][0] = floatx4{0, 0, 0, 0}; o[a][1] = floatx4{0, 0, 0, 0}; }
+                mrow[0] = mrow[1] = -INFINITY; lrow[0] = lrow[1] = 0.f;
+            }
+            return;
+        }
         issue_tile(0, 0);
         if (RING == 3 && ntile > 1) issue_tile(64, 1);
         int slot = 0;
@@ -547,29 +599,7 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
             else tile(kv0, 0, std::false_type{}, M0{});
         }
     }
-    // finish: o[dt][qt][r] <-> d index 16*dt + 4*fg + r, q = q0 + 16*qt + fr
-#pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        float l;
-        if (ONES) l = __shfl(o[DVT - 1][qt][3], 48 + fr);   // row 16*DVT-1 of O^T lives in lane group 3, register 3
-        else {
-            l = lrow[qt];
-            l += __shfl_xor(l, 16);
-            l += __shfl_xor(l, 32);
-        }
-        float inv = 1.0f / l;
-        int q = q0 + qt * 16 + fr;
-        if (q >= p.Sq) continue;
-#pragma unroll
-        for (int dt = 0; dt < DVT; ++dt) {
-            int c = dt * 16 + fg * 4;
-            if (c < d) {
-                half4 h = {(half_t)(o[dt][qt][0] * inv), (half_t)(o[dt][qt][1] * inv), (half_t)(o[dt][qt][2] * inv),
-                           (half_t)(o[dt][qt][3] * inv)};
-                *(half4*)(Ob + (long long)q * p.ldo + c) = h;
-            }
-        }
-    }
+    finish();
 }
 
 // ------------------------------------------------------------------------------------------ plain kernel
@@ -629,6 +659,15 @@ static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
         static const int ring_env = getenv("SDE_ATTN_RING") ? atoi(getenv("SDE_ATTN_RING")) : 2;
         static const int fold_env2 = getenv("SDE_ATTN_FOLD") ? atoi(getenv("SDE_ATTN_FOLD")) : 1;
         // short key ranges (cross-attention: two tiles) keep the deeper ring: with one tile of look-ahead their few loads are all exposed (47.6 -> 54 us measured)
+        // cross-attention (key range within the three ring slots): persistent blocks, two per CU, each walking query blocks of its head
+        static const int persist_env = getenv("SDE_ATTN_PERSIST") ? atoi(getenv("SDE_ATTN_PERSIST")) : 1;   // tuning hook
+        if (persist_env && fold_env2 && p.d < DQK && p.d < DVT * 16 && p.Skv <= 192 && p.Sq >= 1024) {
+            const int nqb = cdiv(p.Sq, 128), pairs = p.heads * p.NB;
+            const int G = std::max(1, std::min(nqb, cdiv(512, pairs)));      // two resident blocks per CU (213 registers)
+            hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, true, 3, true>), dim3(G, p.heads, p.NB), dim3(256), (AttnLayout<DQK, DVT, 3>::SMEM_BYTES),
+                               ctx.stream, p);
+            return;
+        }
         if (ring_env == 2 && fold_env2 && p.d < DQK && p.d < DVT * 16 && p.Skv >= 512) {
             hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, true, 2>), grid, dim3(256), (AttnLayout<DQK, DVT, 2>::SMEM_BYTES), ctx.stream, p);
             return;

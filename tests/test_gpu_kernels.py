@@ -283,6 +283,10 @@ ATTN_CASES = [
     (1, 4, 64, 64, 16),       # tiny test model
     (1, 1, 64, 64, 64),       # tiny VAE attention (single head)
     (1, 2, 33, 7, 12),        # unaligned head dim -> plain kernel
+    (2, 8, 4096, 77, 40),     # cross attention at the 64x64 level: persistent blocks walking query blocks, K / V loaded once
+    (1, 8, 1100, 152, 40),    # same, three key tiles (last ragged), ragged last query block
+    (1, 3, 2048, 192, 40),    # same, exactly three full tiles
+    (1, 8, 4096, 227, 40),    # four key tiles: back on the per-query-block form
 ]
 
 
