@@ -56,7 +56,7 @@ struct AttnLayout {
     static constexpr int KROW = KSWZ ? DQK : DQK + 8;                     // K-tile row (elements)
     static constexpr int VROW = DVT > 5 ? DVT * 16 + 8 : ((DVT & 1) ? DVT * 16 : DVT * 16 + 16);     // V-tile row (elements); wide heads: measured no gain
     static constexpr bool PREFETCH = DVT <= 4;   // wide heads: staging registers are not affordable, those levels are small
-    static constexpr bool DMA = PREFETCH && DQK == 64;
+    static constexpr bool DMA = DQK == 64 || (DQK == 96 && DVT == 5);   // d = 33..64, and d = 80 (SD v1.x 32x32 level; round 3)
     static constexpr int NBUF = DMA ? RING : (PREFETCH ? 2 : 1);  // the register-staged prefetching variants double-buffer: one barrier per tile
     static constexpr int SMEM_BYTES = NBUF * 64 * (KROW + VROW) * 2;
 };
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
             for (int r = 0; r < 4; ++r) { v[r] = l4[r]; v[4 + r] = h4[r]; }
             return v;
         };
-        constexpr bool HOLD_V = DVT <= 4;   // keep the V^T fragments in registers for both q-tiles when they fit
+        constexpr bool HOLD_V = DVT <= 4 || DMA;   // keep the V^T fragments in registers for both q-tiles when they fit (the DMA variants read them from inline asm: always held)
         half8 vf[HOLD_V ? 2 : 1][HOLD_V ? DVT : 1];
         if constexpr (DMA) {
             // The transposed reads are issued from inline asm: the compiler orders every ds_read it can see behind ALL outstanding
@@ -439,7 +439,8 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
     using M0 = std::integral_constant<int, 0>;
 
     if constexpr (DMA) {
-        constexpr int CPR = VROW / 8, VPW = 16 * CPR, NVI = (VPW + 63) / 64, NKI = 2;   // V chunks per row / per wave; DMA instructions per wave
+        constexpr int CPR = VROW / 8, VPW = 16 * CPR, NVI = (VPW + 63) / 64;            // V chunks per row / per wave; DMA instructions per wave
+        constexpr int KCPR = KROW / 8, KPW = 16 * KCPR, NKI = (KPW + 63) / 64;          // K likewise: wave w fills rows 16 w .. 16 w + 15 (KROW = 64: two full pieces)
         const int wu = __builtin_amdgcn_readfirstlane(wid);
         const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, 0x80000000u, 0x00020000);
         const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vb, 0, 0x80000000u, 0x00020000);
@@ -449,8 +450,8 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
         bool k_act[NKI], v_act[NVI];
 #pragma unroll
         for (int j = 0; j < NKI; ++j) {
-            const int id = (wu * NKI + j) * 64 + lane, r = id >> 3, c = (id & 7) ^ (r & 7);
-            k_r[j] = r; k_cb[j] = c * 16; k_act[j] = c * 8 < d;
+            const int idw = j * 64 + lane, id = wu * KPW + idw, r = id / KCPR, cp = id - r * KCPR, c = KSWZ ? (cp ^ (r & 7)) : cp;
+            k_r[j] = r; k_cb[j] = c * 16; k_act[j] = idw < KPW && c * 8 < d;
             k_off[j] = (unsigned)(r * p.ldk * 2 + c * 16);
         }
 #pragma unroll
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
             v_off[j] = (unsigned)(r * p.ldv * 2 + c * 16);
         }
         auto issue_tile = [&](int kv0, int slot) {
-            char* kd = (char*)(sK_ + slot * 64 * KROW) + wu * NKI * 1024;
+            char* kd = (char*)(sK_ + slot * 64 * KROW) + wu * KPW * 16;
             char* vd = (char*)(sV_ + slot * 64 * VROW) + wu * VPW * 16;
             const bool full = kv0 + 64 <= p.Skv;     // block-uniform
             const int ks_ = full ? kv0 * p.ldk * 2 : 0, vs_ = full ? kv0 * p.ldv * 2 : 0;
@@ -479,9 +480,9 @@ __global__ __launch_bounds__(256, (RING == 2 ? 4 : (DVT <= 6 ? 2 : 1))) void att
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int id = tid + i * 256, r = id >> 3, c = (id & 7) ^ (r & 7);
-                if (c * 8 >= d) {
+            for (int i = 0; i < (64 * KCPR + 255) / 256; ++i) {
+                const int id = tid + i * 256, r = id / KCPR, cp = id - r * KCPR, c = KSWZ ? (cp ^ (r & 7)) : cp;
+                if (id < 64 * KCPR && c * 8 >= d) {
                     half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
                     if (FOLD && c * 8 == d) { z[0] = (half_t)1.0f; z[1] = (half_t)1.0f; }
                     *(half8*)(sK_ + b * 64 * KROW + id * 8) = z;
@@ -675,14 +676,16 @@ static void launch_attn_t(const LaunchCtx& ctx, const AttnDev& p)
     }
     constexpr int smem = AttnLayout<DQK, DVT>::SMEM_BYTES;
     static const int fold_env = getenv("SDE_ATTN_FOLD") ? atoi(getenv("SDE_ATTN_FOLD")) : 1;   // tuning hook
-    const bool fold = fold_env && p.d < DQK && DVT <= 4;    // needs two spare score-product columns; wider heads run out of VGPRs (measured slower)
+    const bool fold = fold_env && p.d < DQK && DVT <= 4;    // needs two spare score-product columns; wider heads: measured slower on the staged path (VGPRs), no gain on the d = 80 DMA path (78.3 against 77.6 us)
     const bool ones = p.d < DVT * 16;
+    auto go = [&](auto kern) {
+        if (smem > 64 * 1024) allow_dynamic_lds((const void*)kern, smem);
+        hipLaunchKernelGGL(kern, grid, dim3(256), smem, ctx.stream, p);
+    };
     if (fold) {
-        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, true>), grid, dim3(256), smem, ctx.stream, p);
-        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, true>), grid, dim3(256), smem, ctx.stream, p);
+        if (ones) go(attn_mfma_kernel<DQK, DVT, true, true>); else go(attn_mfma_kernel<DQK, DVT, false, true>);
     } else {
-        if (ones) hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, true, false>), grid, dim3(256), smem, ctx.stream, p);
-        else hipLaunchKernelGGL((attn_mfma_kernel<DQK, DVT, false, false>), grid, dim3(256), smem, ctx.stream, p);
+        if (ones) go(attn_mfma_kernel<DQK, DVT, true, false>); else go(attn_mfma_kernel<DQK, DVT, false, false>);
     }
 }
 
